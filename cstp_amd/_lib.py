@@ -1,0 +1,92 @@
+"""ctypes binding of libcstp_hip.so (the C ABI declared in include/cstp_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load this
+module raises, loudly, at first use.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcstp_hip.so")
+ABI_VERSION = 1
+
+
+class ConvDesc(ctypes.Structure):
+    """struct cstp_conv_desc (include/cstp_hip.h)."""
+    _fields_ = [(n, c_int32) for n in
+                ("n", "c", "d", "h", "w", "k", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class CstpError(RuntimeError):
+    pass
+
+
+_P = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+# name -> (restype, argtypes).  Must list EVERY symbol include/cstp_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+SIGNATURES = {
+    "cstp_abi_version": (c_int32, []),
+    "cstp_last_error": (c_char_p, []),
+    "cstp_conv3d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "cstp_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t]),
+    "cstp_conv3d_backward_data": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "cstp_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float,
+                                        c_float, c_int32, _P, c_size_t]),
+    "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
+                                   c_size_t]),
+    "cstp_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
+    "cstp_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
+    "cstp_channel_sum": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t]),
+    "cstp_byol_loss_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32]),
+    "cstp_byol_loss_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32]),
+    "cstp_cross_entropy_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32]),
+    "cstp_cross_entropy_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32]),
+    "cstp_ntxent_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "cstp_ntxent_forward": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, c_size_t]),
+    "cstp_ntxent_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, c_size_t]),
+    "cstp_ema_update": (c_int32, [_P, _P, _P, c_size_t, c_double]),
+    "cstp_sumsq": (c_int32, [_P, _P, c_size_t, _P, _P, c_size_t]),
+    "cstp_clip_coef": (c_int32, [_P, _P, c_float, _P, _P]),
+    "cstp_sgd_step": (c_int32, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, _P, c_int32, c_int32]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libcstp_hip.so (once).  Raises CstpError when it is absent -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CstpError(
+            "libcstp_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  cstp_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise CstpError("failed to load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CstpError("libcstp_hip.so lacks symbol %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.cstp_abi_version()
+    if ver != ABI_VERSION:
+        raise CstpError("libcstp_hip.so ABI version %d != binding %d (rebuild)" % (ver, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().cstp_last_error()
+        raise CstpError("%s failed: %s" % (what, msg.decode() if msg else "unknown error"))

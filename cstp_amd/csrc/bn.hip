@@ -1,0 +1,310 @@
+// Train-mode BatchNorm (3d and 1d) fused with the residual add and ReLU that follow it, forward and
+// backward.  HBM-streaming kernels: x is read once for the statistics (fp64 accumulators, wave
+// shuffles + LDS for the cross-lane part, deterministic two-stage reduction -- no atomics) and once
+// more for the normalise/activate pass.
+//
+// Layout: x[n][c][s], s = D*H*W contiguous.  For s == 1 (BatchNorm1d over [B][F]) a dedicated
+// single-launch kernel keeps lanes along the contiguous feature axis.
+#include "common.h"
+
+namespace cstp {
+
+static inline int bn_nsplit(int n, int c) {
+  int ns = cdiv(2048, c);
+  if (ns > n) ns = n;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
+// ---- stage 1: per (channel, split) partial sums ------------------------------------------------
+// MODE 0: (sum x, sum x^2)          MODE 1: (sum g, sum g*xhat), g = dy * (relu ? y>0 : 1)
+template <int MODE, bool VEC4>
+__global__ void __launch_bounds__(256)
+bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                 const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int n,
+                 int c, int s, int nsplit, int relu) {
+  __shared__ double sm[16];
+  const int ch = blockIdx.x, j = blockIdx.y;
+  double a0 = 0.0, a1 = 0.0;
+  float mu = 0.f, is = 0.f;
+  if (MODE == 1) { mu = mean[ch]; is = invstd[ch]; }
+  for (int row = j; row < n; row += nsplit) {
+    const size_t base = ((size_t)row * c + ch) * s;
+    if (VEC4) {
+      const float4* xp = reinterpret_cast<const float4*>(x + base);
+      const float4* yp = reinterpret_cast<const float4*>(y + base);
+      const float4* gp = reinterpret_cast<const float4*>(dy + base);
+      const int s4 = s >> 2;
+      for (int i = threadIdx.x; i < s4; i += 256) {
+        const float4 v = xp[i];
+        if (MODE == 0) {
+          a0 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+          a1 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+          float4 g = gp[i];
+          if (relu) {
+            const float4 o = yp[i];
+            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+            g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+          }
+          a0 += (double)g.x + (double)g.y + (double)g.z + (double)g.w;
+          a1 += (double)(g.x * ((v.x - mu) * is)) + (double)(g.y * ((v.y - mu) * is)) +
+                (double)(g.z * ((v.z - mu) * is)) + (double)(g.w * ((v.w - mu) * is));
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < s; i += 256) {
+        const float v = x[base + i];
+        if (MODE == 0) {
+          a0 += (double)v; a1 += (double)v * v;
+        } else {
+          float g = dy[base + i];
+          if (relu && !(y[base + i] > 0.f)) g = 0.f;
+          a0 += (double)g; a1 += (double)(g * ((v - mu) * is));
+        }
+      }
+    }
+  }
+  a0 = block_sum(a0, sm);
+  a1 = block_sum(a1, sm);
+  if (threadIdx.x == 0) {
+    part[((size_t)ch * nsplit + j) * 2 + 0] = a0;
+    part[((size_t)ch * nsplit + j) * 2 + 1] = a1;
+  }
+}
+
+// ---- stage 2 (forward): mean / invstd / running stats ------------------------------------------
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, int c, int nsplit, double count, float eps,
+                                       float momentum) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = 0; j < nsplit; ++j) { s0 += part[((size_t)ch * nsplit + j) * 2]; s1 += part[((size_t)ch * nsplit + j) * 2 + 1]; }
+  const double mu = s0 / count;
+  double var = s1 / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  save_mean[ch] = (float)mu;
+  save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+}
+
+// ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int c, int nsplit) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = 0; j < nsplit; ++j) { s0 += part[((size_t)ch * nsplit + j) * 2]; s1 += part[((size_t)ch * nsplit + j) * 2 + 1]; }
+  dbeta[ch] = (float)s0;
+  dgamma[ch] = (float)s1;
+}
+
+// ---- stage 3 (forward): y = act((x-mean)*invstd*gamma + beta + residual) -----------------------
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                    const float* __restrict__ invstd, size_t total, int c, int s, int relu) {
+  constexpr int W = VEC4 ? 4 : 1;
+  const size_t nvec = total / W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const size_t e = i * W;
+    const int ch = (int)((e / s) % c);
+    const float sc = invstd[ch] * gamma[ch];
+    const float sh = beta[ch] - mean[ch] * sc;
+    if (VEC4) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (res != nullptr) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+      float v = x[e] * sc + sh;
+      if (res != nullptr) v += res[e];
+      if (relu) v = fmaxf(v, 0.f);
+      y[e] = v;
+    }
+  }
+}
+
+// ---- stage 3 (backward): dx = gamma*invstd*(g - dbeta/cnt - xhat*dgamma/cnt); dres = g ---------
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx,
+                    float* __restrict__ dres, size_t total, int c, int s, float inv_count, int relu) {
+  constexpr int W = VEC4 ? 4 : 1;
+  const size_t nvec = total / W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const size_t e = i * W;
+    const int ch = (int)((e / s) % c);
+    const float mu = mean[ch], is = invstd[ch];
+    const float k = gamma[ch] * is;
+    const float mb = dbeta[ch] * inv_count, mg = dgamma[ch] * inv_count;
+    if (VEC4) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 g = reinterpret_cast<const float4*>(dy)[i];
+      if (relu) {
+        const float4 o = reinterpret_cast<const float4*>(y)[i];
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      if (dres != nullptr) reinterpret_cast<float4*>(dres)[i] = g;
+      float4 o;
+      o.x = k * (g.x - mb - (v.x - mu) * is * mg);
+      o.y = k * (g.y - mb - (v.y - mu) * is * mg);
+      o.z = k * (g.z - mb - (v.z - mu) * is * mg);
+      o.w = k * (g.w - mb - (v.w - mu) * is * mg);
+      reinterpret_cast<float4*>(dx)[i] = o;
+    } else {
+      float g = dy[e];
+      if (relu && !(y[e] > 0.f)) g = 0.f;
+      if (dres != nullptr) dres[e] = g;
+      dx[e] = k * (g - mb - (x[e] - mu) * is * mg);
+    }
+  }
+}
+
+// ---- BatchNorm1d (s == 1): one thread per feature, lanes along the contiguous feature axis ------
+__global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                float* __restrict__ save_mean, float* __restrict__ save_invstd, int n, int c, float eps,
+                                float momentum, int relu) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < n; ++r) { const double v = x[(size_t)r * c + ch]; s0 += v; s1 += v * v; }
+  const double mu = s0 / n;
+  double var = s1 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[ch] = (float)mu;
+  save_invstd[ch] = is;
+  if (running_mean != nullptr) {
+    const double unb = n > 1 ? var * n / (n - 1.0) : var;
+    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
+    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  }
+  const float sc = is * gamma[ch], sh = beta[ch] - (float)mu * sc;
+  for (int r = 0; r < n; ++r) {
+    float v = x[(size_t)r * c + ch] * sc + sh;
+    if (res != nullptr) v += res[(size_t)r * c + ch];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(size_t)r * c + ch] = v;
+  }
+}
+
+__global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, float* __restrict__ dx, float* __restrict__ dres,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c, int relu) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float mu = mean[ch], is = invstd[ch];
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < n; ++r) {
+    float g = dy[(size_t)r * c + ch];
+    if (relu && !(y[(size_t)r * c + ch] > 0.f)) g = 0.f;
+    s0 += (double)g;
+    s1 += (double)(g * ((x[(size_t)r * c + ch] - mu) * is));
+  }
+  dbeta[ch] = (float)s0;
+  dgamma[ch] = (float)s1;
+  const float k = gamma[ch] * is, mb = (float)s0 / n, mg = (float)s1 / n;
+  for (int r = 0; r < n; ++r) {
+    float g = dy[(size_t)r * c + ch];
+    if (relu && !(y[(size_t)r * c + ch] > 0.f)) g = 0.f;
+    if (dres != nullptr) dres[(size_t)r * c + ch] = g;
+    dx[(size_t)r * c + ch] = k * (g - mb - (x[(size_t)r * c + ch] - mu) * is * mg);
+  }
+}
+
+static inline int ew_grid(size_t nvec) {
+  size_t b = (nvec + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace cstp
+
+using namespace cstp;
+
+extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s) {
+  (void)s;
+  if (n <= 0 || c <= 0) return 0;
+  return align_up((size_t)c * bn_nsplit(n, c) * 2 * sizeof(double), 256);
+}
+
+extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                     float* save_invstd, int32_t n, int32_t c, int32_t s, float eps, float momentum,
+                                     int32_t relu, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
+  CSTP_REQUIRE((size_t)n * s > 1, "train-mode BatchNorm needs more than 1 value per channel");
+  hipStream_t st = as_stream(stream);
+  if (s == 1) {
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, residual, y, gamma, beta, running_mean,
+                       running_var, save_mean, save_invstd, n, c, eps, momentum, relu);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s), "workspace too small");
+  double* part = reinterpret_cast<double*>(ws);
+  const int ns = bn_nsplit(n, c);
+  const bool v4 = (s % 4) == 0;
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), dim3(c, ns), dim3(256), 0, st, x, x, x, nullptr, nullptr, part, n, c, s, ns, 0);
+  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(c, ns), dim3(256), 0, st, x, x, x, nullptr, nullptr, part, n, c, s, ns, 0);
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
+                     running_var, c, ns, (double)n * s, eps, momentum);
+  CSTP_LAUNCH_CHECK();
+  const size_t total = (size_t)n * c * s;
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, relu);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, relu);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
+                                const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
+                                float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t relu, void* ws,
+                                size_t ws_bytes) {
+  CSTP_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  hipStream_t st = as_stream(stream);
+  if (s == 1) {
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, y, dy, gamma, save_mean, save_invstd, dx,
+                       dresidual, dgamma, dbeta, n, c, relu);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s), "workspace too small");
+  double* part = reinterpret_cast<double*>(ws);
+  const int ns = bn_nsplit(n, c);
+  const bool v4 = (s % 4) == 0;
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(c, ns), dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, n, c, s, ns, relu);
+  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(c, ns), dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, n, c, s, ns, relu);
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, c, ns);
+  CSTP_LAUNCH_CHECK();
+  const size_t total = (size_t)n * c * s;
+  const float inv_count = (float)(1.0 / ((double)n * s));
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, dgamma, dbeta, dx, dresidual, total, c, s, inv_count, relu);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, dgamma, dbeta, dx, dresidual, total, c, s, inv_count, relu);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}

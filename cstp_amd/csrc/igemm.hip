@@ -1,0 +1,575 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X), exact fp32 on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, 157 TF/s dense = the fp32 vector peak).
+//
+// One kernel family serves every GEMM-shaped op of the CSTP step:
+//   K1  igemm_k1<MT, DGRAD, STRADDLE>   out[m][n] = sum_k Wp[k][m] * Xcol[k][n]
+//         forward conv  (m = out channel, n = output position, k = (tap, in channel))
+//         data gradient (m = in channel,  n = input position of one stride-parity class,
+//                        k = (tap, out channel); only the taps that hit the class are visited)
+//   K2  igemm_k2<MT, STRADDLE>          dWp[m][j] += sum_n dY[m][n] * Xcol[j][n]   (weight gradient,
+//         n = output position, split over blocks, fp32 atomics into a packed slab)
+// nn.Linear is the D=H=W=1, 1x1x1 case of the same kernels.
+//
+// Block = 256 threads = 4 waves; block tile (32*MT) x 128; each wave owns a (32*MT) x 32 strip,
+// i.e. MT accumulators of 32x32 (16 VGPRs each).  Operands are staged global -> registers -> LDS
+// (coalesced along n, the NCDHW-contiguous axis) and double buffered in LDS.
+#include "common.h"
+
+namespace cstp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Geom {
+  int Cs, Ds, Hs, Ws;      // gather source tensor [Nb][Cs][Ds][Hs][Ws]
+  int Nb, Dp, Hp, Wp;      // position space (fwd: y dims; dgrad: FULL x dims; wgrad: dy dims)
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int Cp;                  // channels per tap in the packed K / J order
+  int M;                   // valid GEMM rows
+  int Mp;                  // leading dimension of the packed A operand
+  int Ktot;                // ntaps * Cp
+};
+
+// ------------------------------------------------------------------------------------------
+// weight packing: native [k_out][c_in][taps]  ->  K-major GEMM operand, zero padded
+//   forward: Wp[(tap*Cp + c)][m = k_out]        dgrad: Wp[(tap*Cp + k_out)][m = c_in]
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int kout, int cin,
+                                    int ntaps, int Cp, int Mp, int Kp, int dgrad) {
+  const size_t total = (size_t)Kp * Mp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i % Mp);
+    const int k = (int)(i / Mp);
+    const int tap = k / Cp, c = k - tap * Cp;
+    float v = 0.f;
+    if (tap < ntaps) {
+      if (!dgrad) {
+        if (m < kout && c < cin) v = w[((size_t)m * cin + c) * ntaps + tap];
+      } else {
+        if (m < cin && c < kout) v = w[((size_t)c * cin + m) * ntaps + tap];
+      }
+    }
+    wp[i] = v;
+  }
+}
+
+// dw[m][c][tap] = dwp[m][tap*Cp + c]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int M, int cin, int ntaps,
+                                    int Cp, int Jp) {
+  const size_t total = (size_t)M * cin * ntaps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % ntaps);
+    const size_t r = i / ntaps;
+    const int c = (int)(r % cin);
+    const int m = (int)(r / cin);
+    dw[i] = dwp[(size_t)m * Jp + tap * Cp + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: forward / data-gradient implicit GEMM
+// ------------------------------------------------------------------------------------------
+template <int MT, bool DGRAD, bool STRADDLE>
+__global__ void __launch_bounds__(256)
+igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ src, const float* __restrict__ bias,
+         float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
+  constexpr int BM = 32 * MT, BN = 128, BK = 16;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (L2); the n_tiles_m blocks that read the
+  // same input panel get consecutive slots of ONE xcd so the panel is fetched into one L2 once.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mtile = slot % n_tiles_m;
+  const int ntile = (slot / n_tiles_m) * 8 + xcd;
+  if (ntile >= n_tiles_x) return;
+
+  int zt = 0, zh = 0, zw = 0;
+  int Dp = g.Dp, Hp = g.Hp, Wp = g.Wp;
+  if (DGRAD) {
+    int z = blockIdx.y;
+    zw = z % g.sw; z /= g.sw;
+    zh = z % g.sh; zt = z / g.sh;
+    Dp = (g.Dp - zt + g.st - 1) / g.st;
+    Hp = (g.Hp - zh + g.sh - 1) / g.sh;
+    Wp = (g.Wp - zw + g.sw - 1) / g.sw;
+  }
+  const int npos = g.Nb * Dp * Hp * Wp;
+  const int n0 = ntile * BN;
+  if (n0 >= npos) return;
+  const int m0 = mtile * BM;
+
+  const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+  const int khw = g.kh * g.kw, ntaps = g.kt * khw;
+
+  // ---- loader coordinates: this thread gathers column `col` of the B tile, rows krow0 + 2r
+  const int col = t & 127, krow0 = t >> 7;
+  const bool nvalid = (n0 + col) < npos;
+  int nb, npd, nph, npw;
+  {
+    int n = nvalid ? (n0 + col) : 0;
+    npw = n % Wp; n /= Wp;
+    nph = n % Hp; n /= Hp;
+    npd = n % Dp; nb = n / Dp;
+  }
+  const size_t src_b = (size_t)nb * g.Cs * DHWs;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  constexpr int A_F4 = 4 * BM;                   // float4 per A tile (16 rows x BM/4)
+  constexpr int A_ITERS = (A_F4 + 255) / 256;
+  float4 ra0, ra1, ra2;   // named registers (an indexed array here ends up in scratch)
+  ra0 = ra1 = ra2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float rb[8];
+  static_assert(A_ITERS <= 3, "A tile staging assumes at most 3 float4 per thread");
+
+  // iteration state
+  int tap = -1, c0 = 0, it = 0;
+  int toff = 0;
+  bool tvalid = false;
+
+  auto setup_tap = [&](int tp) __attribute__((always_inline)) -> bool {   // returns false if the tap never hits this parity class
+    const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+    int id, ih, iw;
+    if (DGRAD) {
+      const int et = zt + g.pt - dt, eh = zh + g.ph - dh, ew = zw + g.pw - dw;
+      if ((et % g.st) != 0 || (eh % g.sh) != 0 || (ew % g.sw) != 0) return false;
+      id = npd + et / g.st; ih = nph + eh / g.sh; iw = npw + ew / g.sw;
+    } else {
+      id = npd * g.st - g.pt + dt; ih = nph * g.sh - g.ph + dh; iw = npw * g.sw - g.pw + dw;
+    }
+    tvalid = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+    toff = id * HWs + ih * g.Ws + iw;
+    return true;
+  };
+
+  auto first_tile = [&]() __attribute__((always_inline)) -> bool {
+    if (STRADDLE) { it = 0; return g.Ktot > 0; }
+    tap = 0; c0 = 0;
+    while (tap < ntaps && !setup_tap(tap)) ++tap;
+    return tap < ntaps;
+  };
+  auto advance = [&]() __attribute__((always_inline)) -> bool {
+    if (STRADDLE) { ++it; return it * BK < g.Ktot; }
+    c0 += BK;
+    if (c0 < g.Cp) return true;
+    c0 = 0; ++tap;
+    while (tap < ntaps && !setup_tap(tap)) ++tap;
+    return tap < ntaps;
+  };
+
+  auto load_tile = [&]() __attribute__((always_inline)) {
+    const int kbase = STRADDLE ? it * BK : tap * g.Cp + c0;
+    {
+      const float* abase = wp + (size_t)kbase * g.Mp + m0;
+      auto a_at = [&](int i) __attribute__((always_inline)) -> float4 {
+        int idx = t + 256 * i;
+        if (idx >= A_F4) idx = 0;   // tail threads re-read element 0; their LDS store is skipped
+        const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
+        return *reinterpret_cast<const float4*>(abase + (size_t)row * g.Mp + c4 * 4);
+      };
+      ra0 = a_at(0);
+      if (A_ITERS > 1) ra1 = a_at(1);
+      if (A_ITERS > 2) ra2 = a_at(2);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int kr = krow0 + 2 * r;
+      float v = 0.f;
+      if (STRADDLE) {
+        const int k = kbase + kr;
+        if (k < g.Ktot && nvalid) {
+          const int tp = k / g.Cp, c = k - tp * g.Cp;
+          const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+          const int id = npd * g.st - g.pt + dt, ih = nph * g.sh - g.ph + dh, iw = npw * g.sw - g.pw + dw;
+          if (c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws)
+            v = src[src_b + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw];
+        }
+      } else {
+        const int c = c0 + kr;
+        if (tvalid && c < g.Cs) v = src[src_b + (size_t)c * DHWs + toff];
+      }
+      rb[r] = v;
+    }
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    if (t < A_F4) *reinterpret_cast<float4*>(&As[buf][t * 4]) = ra0;
+    if (A_ITERS > 1 && t + 256 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 256) * 4]) = ra1;
+    if (A_ITERS > 2 && t + 512 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 512) * 4]) = ra2;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) Bs[buf][(krow0 + 2 * r) * BN + col] = rb[r];
+  };
+
+  bool have = first_tile();
+  if (have) { load_tile(); store_tile(0); }
+  __syncthreads();
+  int buf = 0;
+  const int lrow = lane >> 5, lcol = lane & 31;
+  while (have) {
+    const bool have_next = advance();
+    if (have_next) load_tile();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int kr = kk + lrow;
+      const float b = Bs[buf][kr * BN + wave * 32 + lcol];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float a = As[buf][kr * BM + mt * 32 + lcol];
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+      }
+    }
+    if (have_next) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    have = have_next;
+  }
+
+  // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int n = n0 + wave * 32 + lcol;
+  if (n < npos) {
+    size_t obase, cstride;
+    if (DGRAD) {
+      int q = n;
+      const int pw = q % Wp; q /= Wp;
+      const int ph = q % Hp; q /= Hp;
+      const int pd = q % Dp; const int b = q / Dp;
+      const int HWf = g.Hp * g.Wp;
+      cstride = (size_t)g.Dp * HWf;
+      obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
+    } else {
+      const int S = Dp * Hp * Wp;
+      const int b = n / S, sp = n - b * S;
+      cstride = (size_t)S;
+      obase = (size_t)b * g.M * cstride + sp;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (m < g.M) {
+          float v = acc[mt][r];
+          if (bias != nullptr) v += bias[m];
+          out[obase + (size_t)m * cstride] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: weight gradient.  dwp[m][j] += sum_{n in split} dy[m][n] * xcol[j][n],  j = tap*Cp + c
+// ------------------------------------------------------------------------------------------
+template <int MT, bool STRADDLE>
+__global__ void __launch_bounds__(256)
+igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
+         int Jp, int ktiles_total, int ktiles_per_split) {
+  constexpr int BM = 32 * MT, BJ = 128, BKN = 64, LD = BKN + 1;
+  __shared__ float As[BM * LD];
+  __shared__ float Bs[BJ * LD];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * BM, j0 = blockIdx.y * BJ;
+  const int S = g.Dp * g.Hp * g.Wp;
+  const int npos = g.Nb * S;
+  const int kt_begin = blockIdx.z * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  if (kt_end > ktiles_total) kt_end = ktiles_total;
+
+  const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+  const int khw = g.kh * g.kw;
+  const int jw0 = j0 + wave * 32;
+  const bool wave_active = jw0 < Jtot;
+  int cw0 = 0, wdt = 0, wdh = 0, wdw = 0;
+  if (!STRADDLE) {
+    const int tapw = jw0 / g.Cp;
+    cw0 = jw0 - tapw * g.Cp;
+    wdt = tapw / khw;
+    const int rr = tapw - wdt * khw;
+    wdh = rr / g.kw; wdw = rr - wdh * g.kw;
+  }
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lrow = lane >> 5, lcol = lane & 31;
+
+  for (int kti = kt_begin; kti < kt_end; ++kti) {
+    const int n = kti * BKN + lane;
+    const bool nvalid = n < npos;
+    int b = 0, sp = 0, od = 0, oh = 0, ow = 0;
+    if (nvalid) {
+      b = n / S; sp = n - b * S;
+      int q = sp;
+      ow = q % g.Wp; q /= g.Wp;
+      oh = q % g.Hp; od = q / g.Hp;
+    }
+    // A tile: dy rows m = wave + 4r
+    {
+      const size_t ab = (size_t)b * g.M * S + sp;
+#pragma unroll
+      for (int r = 0; r < BM / 4; ++r) {
+        const int m = wave + 4 * r;
+        float v = 0.f;
+        if (nvalid && (m0 + m) < g.M) v = dy[ab + (size_t)(m0 + m) * S];
+        As[m * LD + lane] = v;
+      }
+    }
+    // B tile: this wave gathers exactly the 32 columns it consumes
+    if (wave_active) {
+      const size_t xb = (size_t)b * g.Cs * DHWs;
+      if (!STRADDLE) {
+        const int id = od * g.st - g.pt + wdt, ih = oh * g.sh - g.ph + wdh, iw = ow * g.sw - g.pw + wdw;
+        const bool v0 = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
+                        (unsigned)iw < (unsigned)g.Ws;
+        const int toff = id * HWs + ih * g.Ws + iw;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          const int c = cw0 + r;
+          float v = 0.f;
+          if (v0 && c < g.Cs) v = x[xb + (size_t)c * DHWs + toff];
+          Bs[(wave * 32 + r) * LD + lane] = v;
+        }
+      } else {
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r) {
+          const int j = jw0 + r;
+          float v = 0.f;
+          if (nvalid && j < Jtot) {
+            const int tp = j / g.Cp, c = j - tp * g.Cp;
+            const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+            const int id = od * g.st - g.pt + dt, ih = oh * g.sh - g.ph + dh, iw = ow * g.sw - g.pw + dw;
+            if (c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws)
+              v = x[xb + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw];
+          }
+          Bs[(wave * 32 + r) * LD + lane] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave_active) {
+#pragma unroll 8
+      for (int kk = 0; kk < BKN; kk += 2) {
+        const float bv = Bs[(wave * 32 + lcol) * LD + kk + lrow];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float av = As[(mt * 32 + lcol) * LD + kk + lrow];
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int j = jw0 + lcol;
+  if (wave_active && j < Jtot) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (m < g.M) atomicAdd(&dwp[(size_t)m * Jp + j], acc[mt][r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int pick_mt(int M) {
+  int best = 1;
+  double bestc = 1e30;
+  for (int mt = 1; mt <= 5; ++mt) {
+    const int bm = 32 * mt;
+    const double c = (double)cdiv(M, bm) * bm * (1.0 + 0.25 / mt);
+    if (c < bestc - 1e-9) { bestc = c; best = mt; }
+  }
+  return best;
+}
+
+struct ConvPlan {
+  int Do, Ho, Wo, ntaps;
+  // forward
+  int f_mt, f_Cp, f_Mp, f_Kp; bool f_straddle;
+  // dgrad
+  int d_mt, d_Cp, d_Mp, d_Kp;
+  // wgrad
+  int w_mt, w_Cp, w_Jtot, w_Jp; bool w_straddle;
+};
+
+static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
+  if (d.n <= 0 || d.c <= 0 || d.k <= 0 || d.d <= 0 || d.h <= 0 || d.w <= 0) return false;
+  if (d.kt <= 0 || d.kh <= 0 || d.kw <= 0 || d.st <= 0 || d.sh <= 0 || d.sw <= 0) return false;
+  if (d.pt < 0 || d.ph < 0 || d.pw < 0) return false;
+  p.Do = (d.d + 2 * d.pt - d.kt) / d.st + 1;
+  p.Ho = (d.h + 2 * d.ph - d.kh) / d.sh + 1;
+  p.Wo = (d.w + 2 * d.pw - d.kw) / d.sw + 1;
+  if (p.Do <= 0 || p.Ho <= 0 || p.Wo <= 0) return false;
+  p.ntaps = d.kt * d.kh * d.kw;
+  // forward: M = k, gather channels = c
+  p.f_mt = pick_mt(d.k);
+  p.f_straddle = (d.c < 8);
+  p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
+  p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
+  p.f_Mp = cdiv(d.k, 32 * p.f_mt) * 32 * p.f_mt;
+  // dgrad: M = c, gather channels = k
+  p.d_mt = pick_mt(d.c);
+  p.d_Cp = (int)align_up(d.k, 16);
+  p.d_Kp = p.ntaps * p.d_Cp;
+  p.d_Mp = cdiv(d.c, 32 * p.d_mt) * 32 * p.d_mt;
+  // wgrad: M = k, J = (tap, c)
+  p.w_mt = pick_mt(d.k);
+  p.w_straddle = (d.c < 8);
+  p.w_Cp = p.w_straddle ? d.c : (int)align_up(d.c, 32);
+  p.w_Jtot = p.ntaps * p.w_Cp;
+  p.w_Jp = (int)align_up(p.w_Jtot, 32);
+  return true;
+}
+
+static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
+  size_t f = (size_t)p.f_Kp * p.f_Mp, g = (size_t)p.d_Kp * p.d_Mp, w = (size_t)d.k * p.w_Jp;
+  size_t m = f > g ? f : g;
+  if (w > m) m = w;
+  return align_up(m * sizeof(float), 256);
+}
+
+template <bool DGRAD, bool STRADDLE>
+static void launch_k1(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
+                      const float* bias, float* out, int ntx, int ntm) {
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((igemm_k1<1, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+    case 2: hipLaunchKernelGGL((igemm_k1<2, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+    case 3: hipLaunchKernelGGL((igemm_k1<3, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+    case 4: hipLaunchKernelGGL((igemm_k1<4, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+    default: hipLaunchKernelGGL((igemm_k1<5, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+  }
+}
+
+template <bool STRADDLE>
+static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* dy, const float* x, float* dwp,
+                      int Jtot, int Jp, int kt_total, int kt_per) {
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((igemm_k2<1, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+    case 2: hipLaunchKernelGGL((igemm_k2<2, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+    case 3: hipLaunchKernelGGL((igemm_k2<3, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+    case 4: hipLaunchKernelGGL((igemm_k2<4, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+    default: hipLaunchKernelGGL((igemm_k2<5, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+  }
+}
+
+static int pack_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace cstp
+
+using namespace cstp;
+
+extern "C" size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
+  ConvPlan p;
+  if (desc == nullptr || !make_plan(*desc, p)) return 0;
+  return plan_ws_bytes(*desc, p);
+}
+
+extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
+                                   const float* bias, float* y, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(desc && x && w && y && ws, "null argument");
+  ConvPlan p;
+  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
+  const cstp_conv_desc& d = *desc;
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
+               "tensor too large for 32-bit plane offsets");
+  hipStream_t s = as_stream(stream);
+  float* wp = reinterpret_cast<float*>(ws);
+  const size_t tot = (size_t)p.f_Kp * p.f_Mp;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp,
+                     p.f_Kp, 0);
+  Geom g;
+  g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;
+  g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;
+  g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
+  g.Cp = p.f_Cp; g.M = d.k; g.Mp = p.f_Mp; g.Ktot = p.ntaps * p.f_Cp;
+  const int npos = d.n * p.Do * p.Ho * p.Wo;
+  const int ntx = cdiv(npos, 128), ntm = cdiv(d.k, 32 * p.f_mt);
+  dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
+  if (p.f_straddle) launch_k1<false, true>(p.f_mt, grid, s, g, wp, x, bias, y, ntx, ntm);
+  else launch_k1<false, false>(p.f_mt, grid, s, g, wp, x, bias, y, ntx, ntm);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
+                                         float* dx, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(desc && dy && w && dx && ws, "null argument");
+  ConvPlan p;
+  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
+  const cstp_conv_desc& d = *desc;
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
+               "tensor too large for 32-bit plane offsets");
+  hipStream_t s = as_stream(stream);
+  float* wp = reinterpret_cast<float*>(ws);
+  const size_t tot = (size_t)p.d_Kp * p.d_Mp;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp,
+                     p.d_Kp, 1);
+  Geom g;
+  g.Cs = d.k; g.Ds = p.Do; g.Hs = p.Ho; g.Ws = p.Wo;     // gather from dy
+  g.Nb = d.n; g.Dp = d.d; g.Hp = d.h; g.Wp = d.w;         // FULL x dims; classes subsample inside
+  g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
+  g.Cp = p.d_Cp; g.M = d.c; g.Mp = p.d_Mp; g.Ktot = p.ntaps * p.d_Cp;
+  const int nclass = d.st * d.sh * d.sw;
+  const int npos_max = d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw);
+  const int ntx = cdiv(npos_max, 128), ntm = cdiv(d.c, 32 * p.d_mt);
+  dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
+  launch_k1<true, false>(p.d_mt, grid, s, g, wp, dy, nullptr, dx, ntx, ntm);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x, const float* dy,
+                                           float* dw, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(desc && x && dy && dw && ws, "null argument");
+  ConvPlan p;
+  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
+  const cstp_conv_desc& d = *desc;
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
+               "tensor too large for 32-bit plane offsets");
+  hipStream_t s = as_stream(stream);
+  float* dwp = reinterpret_cast<float*>(ws);
+  const size_t slab = (size_t)d.k * p.w_Jp * sizeof(float);
+  if (hipMemsetAsync(dwp, 0, slab, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+  Geom g;
+  g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;         // gather from x
+  g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;      // reduction over dy positions
+  g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
+  g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
+  const int npos = d.n * p.Do * p.Ho * p.Wo;
+  const int kt_total = cdiv(npos, 64);
+  const int ntm = cdiv(d.k, 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
+  int splits = cdiv(1024, ntm * ntj);
+  if (splits > cdiv(kt_total, 4)) splits = cdiv(kt_total, 4);
+  if (splits < 1) splits = 1;
+  const int kt_per = cdiv(kt_total, splits);
+  splits = cdiv(kt_total, kt_per);
+  dim3 grid((unsigned)ntm, (unsigned)ntj, (unsigned)splits);
+  if (p.w_straddle) launch_k2<true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per);
+  else launch_k2<false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per);
+  CSTP_LAUNCH_CHECK();
+  const size_t tot = (size_t)d.k * d.c * p.ntaps;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,332 @@
+"""torch.autograd wrappers over the C ABI (libcstp_hip.so).  PyTorch supplies device memory,
+streams and the autograd graph; every FLOP/byte of the hot path runs in the HIP kernels.
+
+There is deliberately NO CPU implementation here: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+_ws_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch arena (grown geometrically, never shrunk).  All kernels of one op are
+    enqueued on the current stream, so one arena per (device, stream) is race-free."""
+    key = (device.index, _stream())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        newn = max(nbytes, 1 << 20)
+        if ws is not None:
+            newn = max(newn, 2 * ws.numel())
+        ws = torch.empty(newn, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.CstpError("%s must be on a HIP device (cstp_amd has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise _lib.CstpError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+def _desc(x_shape, w_shape, stride, padding) -> ConvDesc:
+    n, c, d, h, w = x_shape
+    k, c2, kt, kh, kw = w_shape
+    if c2 != c:
+        raise _lib.CstpError("conv3d: input has %d channels, weight expects %d" % (c, c2))
+    return ConvDesc(n, c, d, h, w, k, kt, kh, kw, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2])
+
+
+def conv_out_shape(x_shape, w_shape, stride, padding):
+    n, _, d, h, w = x_shape
+    k, _, kt, kh, kw = w_shape
+    return (n, k, (d + 2 * padding[0] - kt) // stride[0] + 1, (h + 2 * padding[1] - kh) // stride[1] + 1,
+            (w + 2 * padding[2] - kw) // stride[2] + 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution / linear
+# ----------------------------------------------------------------------------------------------
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding):
+        lib = _lib.load()
+        x = _req(x, "conv3d input")
+        w = _req(w, "conv3d weight")
+        desc = _desc(x.shape, w.shape, stride, padding)
+        y = torch.empty(conv_out_shape(x.shape, w.shape, stride, padding), dtype=torch.float32, device=x.device)
+        nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
+        ws = _workspace(x.device, nbytes)
+        b = None if bias is None else _req(bias, "conv3d bias")
+        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(),
+                                      ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
+        ctx.save_for_backward(x, w)
+        ctx.desc = desc
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _req(dy, "conv3d grad_output")
+        nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
+        ws = _workspace(x.device, nbytes)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                                                  ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_weight")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            n, k = dy.shape[0], dy.shape[1]
+            s = dy.numel() // (n * k)
+            db = torch.empty(k, dtype=torch.float32, device=dy.device)
+            check(lib.cstp_channel_sum(_stream(), dy.data_ptr(), db.data_ptr(), n, k, s, None, 0), "cstp_channel_sum")
+        return dx, dw, db, None, None
+
+
+def conv3d(x, w, bias=None, stride=1, padding=0):
+    """F.conv3d drop-in (fp32, NCDHW)."""
+    return _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding))
+
+
+def linear(x, w, bias=None):
+    """F.linear drop-in for 2-D x: the 1x1x1 convolution over [B][F][1][1][1]."""
+    y = _Conv3d.apply(x.reshape(x.shape[0], x.shape[1], 1, 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1, 1), bias,
+                      (1, 1, 1), (0, 0, 0))
+    return y.reshape(x.shape[0], w.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------
+# train-mode BatchNorm (+ residual) (+ ReLU)
+# ----------------------------------------------------------------------------------------------
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum):
+        lib = _lib.load()
+        x = _req(x, "batch_norm input")
+        gamma = _req(gamma, "batch_norm weight")
+        beta = _req(beta, "batch_norm bias")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        res = None if residual is None else _req(residual, "residual")
+        if res is not None and res.shape != x.shape:
+            raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        nbytes = lib.cstp_bn_workspace_bytes(n, c, s)
+        ws = _workspace(x.device, nbytes)
+        check(lib.cstp_bn_forward_train(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), n, c, s,
+                                        eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
+              "cstp_bn_forward_train")
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = relu
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = _req(dy, "batch_norm grad_output")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        nbytes = lib.cstp_bn_workspace_bytes(n, c, s)
+        ws = _workspace(x.device, nbytes)
+        check(lib.cstp_bn_backward(_stream(), x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                   invstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n, c, s,
+                                   1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual=None, relu=False, eps=BN_EPS,
+                   momentum=BN_MOMENTUM):
+    """y = act(batch_norm_train(x) + residual); running stats updated in place."""
+    return _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum))
+
+
+# ----------------------------------------------------------------------------------------------
+# global average pool
+# ----------------------------------------------------------------------------------------------
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req(x, "avgpool input")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(lib.cstp_avgpool_forward(_stream(), x.data_ptr(), y.data_ptr(), n * c, s), "cstp_avgpool_forward")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _req(dy, "avgpool grad_output")
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        n, c = ctx.shape[0], ctx.shape[1]
+        s = dx.numel() // (n * c)
+        check(lib.cstp_avgpool_backward(_stream(), dy.data_ptr(), dx.data_ptr(), n * c, s), "cstp_avgpool_backward")
+        return dx
+
+
+def global_avg_pool(x):
+    """AdaptiveAvgPool3d(1) + view(-1, C)."""
+    return _AvgPool.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+class _ByolLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        x = _req(x, "byol x")
+        y = _req(y, "byol y")
+        b, f = x.shape
+        loss = torch.empty(b, dtype=torch.float32, device=x.device)
+        check(lib.cstp_byol_loss_forward(_stream(), x.data_ptr(), y.data_ptr(), loss.data_ptr(), b, f), "cstp_byol_loss_forward")
+        ctx.save_for_backward(x, y)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        x, y = ctx.saved_tensors
+        dloss = _req(dloss, "byol grad_output")
+        dx = torch.empty_like(x)
+        check(lib.cstp_byol_loss_backward(_stream(), x.data_ptr(), y.data_ptr(), dloss.data_ptr(), dx.data_ptr(), x.shape[0],
+                                          x.shape[1]), "cstp_byol_loss_backward")
+        return dx, None
+
+
+def byol_regression_loss(x, y):
+    """2 - 2*cos(x, y) per row; y is treated as a constant (the detached target projection)."""
+    return _ByolLoss.apply(x, y.detach())
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _lib.load()
+        logits = _req(logits, "cross_entropy logits")
+        if labels.dtype != torch.int64 or not labels.is_cuda:
+            raise _lib.CstpError("cross_entropy labels must be int64 on the HIP device")
+        labels = labels.contiguous()
+        b, k = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        check(lib.cstp_cross_entropy_forward(_stream(), logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), b, k),
+              "cstp_cross_entropy_forward")
+        ctx.save_for_backward(logits, labels)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, labels = ctx.saved_tensors
+        dloss = _req(dloss.reshape(1), "cross_entropy grad_output")
+        dl = torch.empty_like(logits)
+        check(lib.cstp_cross_entropy_backward(_stream(), logits.data_ptr(), labels.data_ptr(), dloss.data_ptr(), dl.data_ptr(),
+                                              logits.shape[0], logits.shape[1]), "cstp_cross_entropy_backward")
+        return dl, None
+
+
+def cross_entropy(logits, labels):
+    """nn.CrossEntropyLoss() (mean reduction)."""
+    return _CrossEntropy.apply(logits, labels)
+
+
+class _NTXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reps, temperature):
+        lib = _lib.load()
+        reps = _req(reps, "ntxent representations")
+        two_n, f = reps.shape
+        nbytes = lib.cstp_ntxent_workspace_bytes(two_n, f)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=reps.device)  # private: lives until backward
+        loss = torch.empty(1, dtype=torch.float32, device=reps.device)
+        check(lib.cstp_ntxent_forward(_stream(), reps.data_ptr(), loss.data_ptr(), two_n, f, temperature, ws.data_ptr(),
+                                      ws.numel()), "cstp_ntxent_forward")
+        ctx.save_for_backward(reps, ws)
+        ctx.temperature = temperature
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        reps, ws = ctx.saved_tensors
+        dloss = _req(dloss.reshape(1), "ntxent grad_output")
+        dreps = torch.empty_like(reps)
+        check(lib.cstp_ntxent_backward(_stream(), reps.data_ptr(), dloss.data_ptr(), dreps.data_ptr(), reps.shape[0],
+                                       reps.shape[1], ctx.temperature, ws.data_ptr(), ws.numel()), "cstp_ntxent_backward")
+        return dreps, None
+
+
+def ntxent(reps, temperature):
+    """NT-Xent over reps = cat(zjs, zis) [2N, F] (loss/NTXent.py:46-62)."""
+    return _NTXent.apply(reps, float(temperature))
+
+
+# ----------------------------------------------------------------------------------------------
+# flat-arena utilities (no autograd)
+# ----------------------------------------------------------------------------------------------
+def ema_update_(target: torch.Tensor, online: torch.Tensor, m: float) -> None:
+    lib = _lib.load()
+    assert target.is_cuda and target.is_contiguous() and online.is_contiguous() and target.numel() == online.numel()
+    check(lib.cstp_ema_update(_stream(), target.data_ptr(), online.data_ptr(), target.numel(), float(m)), "cstp_ema_update")
+
+
+def grad_sumsq(g: torch.Tensor, out: torch.Tensor) -> None:
+    lib = _lib.load()
+    ws = _workspace(g.device, 8192)
+    check(lib.cstp_sumsq(_stream(), g.data_ptr(), g.numel(), out.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_sumsq")
+
+
+def clip_coef(sumsq: torch.Tensor, max_norm: float, coef: torch.Tensor, norm_out: Optional[torch.Tensor]) -> None:
+    lib = _lib.load()
+    check(lib.cstp_clip_coef(_stream(), sumsq.data_ptr(), float(max_norm), coef.data_ptr(), _ptr(norm_out)), "cstp_clip_coef")
+
+
+def sgd_step_(p, g, buf, lr: torch.Tensor, momentum: float, weight_decay: float, coef: Optional[torch.Tensor],
+              first_step: bool, write_back_grad: bool = True) -> None:
+    lib = _lib.load()
+    check(lib.cstp_sgd_step(_stream(), p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr.data_ptr(), float(momentum),
+                            float(weight_decay), _ptr(coef), 1 if first_step else 0, 1 if write_back_grad else 0),
+          "cstp_sgd_step")

@@ -1,0 +1,381 @@
+"""R(2+1)D-BYOL for MI355X -- host-side mirror of the reference model interface.
+
+Mirrors (same class names, attribute names, state-dict keys, argument meaning and error
+behaviour) /root/reference/models/pace/r21d_byol.py:
+  SpatioTemporalConv :38-97, SpatioTemporalResBlock :100-148, SpatioTemporalResLayer :151-181,
+  R2Plus1DNet :184-229, Projector :232-243, Predictor :246-257, R21DBYOL :260-401.
+The module tree only holds parameters/buffers and sequences kernel launches; all arithmetic
+runs in the HIP kernels of libcstp_hip.so (cstp_amd.ops).  Differences from the reference,
+all additive:
+  * ``layer_sizes`` is a constructor argument of R21DBYOL (the reference hard-codes (1,1,1,1),
+    :268-269) so --model_depth 18/34 means R(2+1)D-18/34;
+  * BN+ReLU and BN+residual+ReLU are single fused ops;
+  * parameters live in flat HBM arenas (``flatten_parameters``) so EMA / clip / SGD are one
+    streaming kernel each instead of ~80 tiny ones (:331-337 rebinding .data per tensor).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LAYER_SIZES = {1: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+
+
+def layer_sizes_for_depth(depth: int) -> Tuple[int, int, int, int]:
+    if int(depth) not in LAYER_SIZES:
+        raise ValueError("r21d_byol supports --model_depth in %s, got %r" % (sorted(LAYER_SIZES), depth))
+    return LAYER_SIZES[int(depth)]
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+# ---------------------------------------------------------------------------------------------
+# leaf modules: parameter holders with nn.Conv3d / nn.BatchNormNd / nn.Linear compatible
+# attribute names and default initialisers (so the CPU RNG stream is consumed identically)
+# ---------------------------------------------------------------------------------------------
+class Conv3d(nn.Module):
+    """nn.Conv3d(bias=False) stand-in; weight [out, in, kt, kh, kw]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("the CSTP path uses bias-free convolutions (r21d_byol.py:52)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + self.kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv3d.reset_parameters
+
+    def forward(self, x):
+        return ops.conv3d(x, self.weight, None, self.stride, self.padding)
+
+
+class _BatchNorm(nn.Module):
+    """Train-mode batch norm with optional fused residual add and ReLU."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, residual=None, relu=False):
+        if not self.training:
+            raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
+        y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps,
+                               self.momentum)
+        self.num_batches_tracked += 1
+        return y
+
+
+class BatchNorm3d(_BatchNorm):
+    pass
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Linear.reset_parameters
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class ReLU(nn.Module):
+    """Placeholder keeping the reference's Sequential indices (net.2); ReLU itself is fused into BN."""
+
+    def forward(self, x):  # pragma: no cover - never called on the fused path
+        raise RuntimeError("ReLU is fused into the preceding BatchNorm kernel")
+
+
+class _MLP(nn.Sequential):
+    """Linear -> BatchNorm1d -> ReLU -> Linear with the reference's Sequential indices 0,1,2,3."""
+
+    def __init__(self, dim, hidden, out):
+        super().__init__(Linear(dim, hidden), BatchNorm1d(hidden), ReLU(), Linear(hidden, out))
+
+    def forward(self, x):
+        if x.shape[0] < 2:
+            # same failure the reference hits in nn.BatchNorm1d (train mode)
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        h = self[0](x)
+        h = self[1](h, relu=True)
+        return self[3](h)
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference module hierarchy
+# ---------------------------------------------------------------------------------------------
+class SpatioTemporalConv(nn.Module):
+    """(2+1)D factored conv: spatial 1xkxk -> BN -> ReLU -> temporal tx1x1 (r21d_byol.py:38-97)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, first_conv=False):
+        super().__init__()
+        kernel_size, stride, padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        intermed_channels = int(math.floor(
+            (kernel_size[0] * kernel_size[1] * kernel_size[2] * in_channels * out_channels) /
+            (kernel_size[1] * kernel_size[2] * in_channels + kernel_size[0] * out_channels)))
+        self.spatial_conv = Conv3d(in_channels, intermed_channels, (1, kernel_size[1], kernel_size[2]),
+                                   stride=(1, stride[1], stride[2]), padding=(0, padding[1], padding[2]), bias=bias)
+        self.bn = BatchNorm3d(intermed_channels)
+        self.relu = ReLU()
+        self.temporal_conv = Conv3d(intermed_channels, out_channels, (kernel_size[0], 1, 1), stride=(stride[0], 1, 1),
+                                    padding=(padding[0], 0, 0), bias=bias)
+
+    def forward(self, x):
+        x = self.bn(self.spatial_conv(x), relu=True)
+        return self.temporal_conv(x)
+
+
+class SpatioTemporalResBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, downsample=False):
+        super().__init__()
+        self.downsample = downsample
+        padding = kernel_size // 2
+        if self.downsample:
+            self.downsampleconv = SpatioTemporalConv(in_channels, out_channels, 1, stride=2)
+            self.downsamplebn = BatchNorm3d(out_channels)
+            self.conv1 = SpatioTemporalConv(in_channels, out_channels, kernel_size, padding=padding, stride=2)
+        else:
+            self.conv1 = SpatioTemporalConv(in_channels, out_channels, kernel_size, padding=padding)
+        self.bn1 = BatchNorm3d(out_channels)
+        self.relu1 = ReLU()
+        self.conv2 = SpatioTemporalConv(out_channels, out_channels, kernel_size, padding=padding)
+        self.bn2 = BatchNorm3d(out_channels)
+        self.outrelu = ReLU()
+
+    def forward(self, x):
+        res = self.bn1(self.conv1(x), relu=True)
+        res = self.conv2(res)
+        if self.downsample:
+            x = self.downsamplebn(self.downsampleconv(x))
+        # relu(x + bn2(res)) as one kernel (r21d_byol.py:143,148)
+        return self.bn2(res, residual=x, relu=True)
+
+
+class SpatioTemporalResLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, layer_size, block_type=SpatioTemporalResBlock,
+                 downsample=False):
+        super().__init__()
+        self.block1 = block_type(in_channels, out_channels, kernel_size, downsample)
+        self.blocks = nn.ModuleList([])
+        for _ in range(layer_size - 1):
+            self.blocks += [block_type(out_channels, out_channels, kernel_size)]
+
+    def forward(self, x):
+        x = self.block1(x)
+        for block in self.blocks:
+            x = block(x)
+        return x
+
+
+class Projector(nn.Module):
+    def __init__(self, dim, projection_size, projection_hidden_size=4096):
+        super().__init__()
+        self.net = _MLP(dim, projection_hidden_size, projection_size)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Predictor(nn.Module):
+    def __init__(self, dim, prediction_size, prediction_hidden_size=4096):
+        super().__init__()
+        self.net = _MLP(dim, prediction_hidden_size, prediction_size)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class R2Plus1DNet(nn.Module):
+    def __init__(self, layer_sizes=(1, 1, 1, 1), block_type=SpatioTemporalResBlock, proj_flag=False):
+        super().__init__()
+        self.conv1 = SpatioTemporalConv(3, 64, (3, 7, 7), stride=(1, 2, 2), padding=(1, 3, 3))
+        self.bn1 = BatchNorm3d(64)
+        self.relu1 = ReLU()
+        self.conv2 = SpatioTemporalResLayer(64, 64, 3, layer_sizes[0], block_type=block_type)
+        self.conv3 = SpatioTemporalResLayer(64, 128, 3, layer_sizes[1], block_type=block_type, downsample=True)
+        self.conv4 = SpatioTemporalResLayer(128, 256, 3, layer_sizes[2], block_type=block_type, downsample=True)
+        self.conv5 = SpatioTemporalResLayer(256, 512, 3, layer_sizes[3], block_type=block_type, downsample=True)
+        self.proj_flag = proj_flag
+        if self.proj_flag:
+            self.project = Projector(dim=512, projection_size=512, projection_hidden_size=4096)
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.conv2(x)
+        x = self.conv3(x)
+        x = self.conv4(x)
+        x = self.conv5(x)
+        x = ops.global_avg_pool(x)  # AdaptiveAvgPool3d(1) + view(-1, 512)
+        if self.proj_flag:
+            return x, self.project(x)
+        return x
+
+
+class R21DBYOL(nn.Module):
+    """forward(x1, x2, o_type='loss_com') -> (loss_byol, (pred_spa, pred_tem, pred_pb_1, pred_pb_2,
+    pred_rot_1, pred_rot_2)) exactly as r21d_byol.py:357-382."""
+
+    def __init__(self, pretrain=True, momentum=0.996, layer_sizes=(1, 1, 1, 1), **kwargs):
+        super().__init__()
+        if not pretrain:
+            raise NotImplementedError("cstp_amd implements the pre-training path (pretrain=True); fine-tune/test "
+                                      "(r21d_byol.py:293-299,394-399) is a later scope row")
+        self.momentum = momentum
+        self.layer_sizes = tuple(layer_sizes)
+        self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+        self.target_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+        self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
+        self._set_grad(self.target_net, False)
+        self.overlap_spa = _MLP(1024, 1024, 5)
+        self.overlap_tem = _MLP(1024, 1024, 5)
+        self.pb_cls = _MLP(512, 512, 5)
+        self.rotate_cls = _MLP(512, 512, 5)
+        # Glorot-uniform overwrite of every Linear/Conv3d/BatchNorm weight, in modules() order
+        # (r21d_byol.py:301-329) -- BN gamma becomes U(+-sqrt(6/C)), not 1.
+        for m in self.modules():
+            if isinstance(m, (Linear, Conv3d, BatchNorm1d, BatchNorm3d)):
+                self._glorot_uniform(m.weight)
+        self._arenas = None
+
+    # -- init helpers (r21d_byol.py:311-329) ---------------------------------------------------
+    @staticmethod
+    def _calculate_fan_in_and_fan_out(tensor):
+        if tensor.dim() < 2:
+            return int(tensor.size(0) / 2), int(tensor.size(0) / 2)
+        receptive = tensor[0][0].numel() if tensor.dim() > 2 else 1
+        return tensor.size(1) * receptive, tensor.size(0) * receptive
+
+    @torch.no_grad()
+    def _glorot_uniform(self, tensor):
+        fan_in, fan_out = self._calculate_fan_in_and_fan_out(tensor)
+        std = math.sqrt(6.0 / float(fan_in + fan_out))
+        return tensor.uniform_(-std, std)
+
+    def _set_grad(self, model, val):
+        for p in model.parameters():
+            p.requires_grad = val
+
+    # -- flat HBM arenas --------------------------------------------------------------------------
+    def trainable_parameters(self) -> List[nn.Parameter]:
+        """online_net, predictor, heads -- in parameters() order (the optimizer's order)."""
+        return [p for p in self.parameters() if p.requires_grad]
+
+    @torch.no_grad()
+    def flatten_parameters(self):
+        """Re-home parameters, gradients and BN counters into flat arenas on the module's device:
+          train arena  = [online_net params | predictor | heads]   (+ same-layout grad arena)
+          target arena = [target_net params]  with the layout of the online_net prefix
+        Each tensor starts on a 16-byte boundary (float4 streaming).  Idempotent."""
+        if self._arenas is not None:
+            return self._arenas
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("flatten_parameters() needs the model on a HIP device (call .cuda() first)")
+
+        def layout(params):
+            offs, n = [], 0
+            for p in params:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4
+            return offs, n
+
+        train = self.trainable_parameters()
+        online = list(self.online_net.parameters())
+        target = list(self.target_net.parameters())
+        assert [p.shape for p in online] == [p.shape for p in target]
+        assert all(a is b for a, b in zip(train[:len(online)], online)), "online_net must lead the trainable order"
+        offs, n_train = layout(train)
+        _, n_enc = layout(online)
+        p_arena = torch.zeros(n_train, dtype=torch.float32, device=dev)
+        g_arena = torch.zeros(n_train, dtype=torch.float32, device=dev)
+        t_arena = torch.zeros(n_enc, dtype=torch.float32, device=dev)
+        for p, o in zip(train, offs):
+            v = p_arena[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = g_arena[o:o + p.numel()].view_as(p)
+        for p, o in zip(target, offs[:len(target)]):
+            v = t_arena[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+        # one int64 arena per net for the BN counters: a single add_ per forward instead of 24+
+        nbt = {}
+        for name, net in (("online", self.online_net), ("target", self.target_net), ("heads", None)):
+            mods = []
+            if net is not None:
+                mods = [m for m in net.modules() if isinstance(m, _BatchNorm)]
+            else:
+                for h in (self.predictor, self.overlap_spa, self.overlap_tem, self.pb_cls, self.rotate_cls):
+                    mods += [m for m in h.modules() if isinstance(m, _BatchNorm)]
+            arena = torch.zeros(len(mods), dtype=torch.long, device=dev)
+            for i, m in enumerate(mods):
+                arena[i] = m.num_batches_tracked
+                m.num_batches_tracked = arena[i]
+            nbt[name] = arena
+        self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
+        return self._arenas
+
+    def _update_target_net(self):
+        """EMA of the online encoder+projector into the target (r21d_byol.py:331-337)."""
+        if self._arenas is not None:
+            a = self._arenas
+            ops.ema_update_(a["target"], a["param"][:a["n_encoder"]], self.momentum)
+        else:
+            for pq, pk in zip(self.online_net.parameters(), self.target_net.parameters()):
+                ops.ema_update_(pk.data, pq.data, self.momentum)
+
+    def _loss_fn(self, x, y):
+        return ops.byol_regression_loss(x, y)
+
+    def _cal_loss(self, online_feat_1, online_feat_2, target_feat_1, target_feat_2):
+        return self._loss_fn(online_feat_1, target_feat_2) + self._loss_fn(online_feat_2, target_feat_1)
+
+    def forward(self, x1, x2=None, o_type=None):
+        if o_type == "loss_com":
+            online_feat_1, online_feat_1_proj = self.online_net(x1)
+            online_feat_2, online_feat_2_proj = self.online_net(x2)
+            online_feat_1_pred = self.predictor(online_feat_1_proj)
+            online_feat_2_pred = self.predictor(online_feat_2_proj)
+            with torch.no_grad():
+                self._update_target_net()
+                _, target_feat_1_proj = self.target_net(x1)
+                _, target_feat_2_proj = self.target_net(x2)
+            loss = self._cal_loss(online_feat_1_pred, online_feat_2_pred, target_feat_1_proj.detach(),
+                                  target_feat_2_proj.detach())
+            feat_cat = torch.cat((online_feat_1, online_feat_2), dim=1)
+            pred_spa = self.overlap_spa(feat_cat)
+            pred_tem = self.overlap_tem(feat_cat)
+            pred_pb_1 = self.pb_cls(online_feat_1)
+            pred_pb_2 = self.pb_cls(online_feat_2)
+            pred_rot_1 = self.rotate_cls(online_feat_1)
+            pred_rot_2 = self.rotate_cls(online_feat_2)
+            # kept for the NT-Xent head and for parity tests (detached views, no extra work)
+            self.last_projections = (online_feat_1_proj, online_feat_2_proj)
+            return loss.mean(), (pred_spa, pred_tem, pred_pb_1, pred_pb_2, pred_rot_1, pred_rot_2)
+        elif o_type == "r_byol":
+            raise NotImplementedError("o_type='r_byol' is shape-broken in the reference (predictor fed a tuple, "
+                                      "r21d_byol.py:384-385); use o_type='loss_com'")
+        elif o_type in ["ft_fc", "ft_all", "test"]:
+            raise NotImplementedError("fine-tune / test outputs are outside the pre-training path")
+        else:
+            raise ValueError("Output cls is not exist!")

@@ -1,0 +1,119 @@
+/*
+ * cstp_hip.h -- C ABI of libcstp_hip.so: the MI355X (gfx950) kernels behind the CSTP
+ * R(2+1)D-BYOL pre-training step.
+ *
+ * The reference (KT27-A/CSTP) owns no native code and no FFI: every op below is an ATen
+ * call-site of its Python hot path, cited per entry point (paths relative to the
+ * reference root).  A maintainer binds this library with ctypes;
+ * cstp_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, NCDHW ([N][C][D][H][W]); 2-D [B][F] tensors are the
+ *     D=H=W=1 case.  Labels are int64.
+ *   - every pointer is a DEVICE pointer on the current HIP device; `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream).  Nothing here allocates, frees, copies to the
+ *     host or synchronises: calls only enqueue work (graph-capture safe).  Scratch comes from
+ *     the caller through (ws, ws_bytes); query the size with the *_workspace_bytes functions.
+ *   - return value: 0 on success, non-zero on error; cstp_last_error() returns a message for
+ *     the calling thread.  No global mutable state besides that thread-local string.
+ */
+#ifndef CSTP_HIP_H
+#define CSTP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSTP_ABI_VERSION 1
+
+/* Geometry of one nn.Conv3d(bias=False) call-site.
+ * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
+ * nn.Linear (r21d_byol.py:235-241, 249-255, 276-291) is the D=H=W=1, k=1 case. */
+typedef struct cstp_conv_desc {
+  int32_t n, c, d, h, w; /* input  [n][c][d][h][w]            */
+  int32_t k;             /* output channels                    */
+  int32_t kt, kh, kw;    /* kernel                             */
+  int32_t st, sh, sw;    /* stride                             */
+  int32_t pt, ph, pw;    /* zero padding                       */
+} cstp_conv_desc;
+
+int cstp_abi_version(void);
+const char* cstp_last_error(void);
+
+/* ---- convolution (F.conv3d / F.linear and their autograd) ------------------------------- */
+size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc);
+/* y[n][k][do][ho][wo] = conv3d(x, w) (+ bias[k] when bias != NULL).  w is [k][c][kt][kh][kw]. */
+int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
+                        const float* bias, float* y, void* ws, size_t ws_bytes);
+/* dx = conv3d input gradient (aten::convolution_backward, input mask). */
+int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
+                              float* dx, void* ws, size_t ws_bytes);
+/* dw = conv3d weight gradient, [k][c][kt][kh][kw] (aten::convolution_backward, weight mask). */
+int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x, const float* dy,
+                                float* dw, void* ws, size_t ws_bytes);
+
+/* ---- BatchNorm3d / BatchNorm1d in TRAIN mode, fused with the residual add and ReLU that follow
+ *      it (r21d_byol.py:83-84,133-134,138-139,148,199-200,216; Projector/Predictor/heads BN1d).
+ *      x,y,residual: [n][c][s] (s = D*H*W).  y = act(bn(x) + residual), act = relu if relu != 0.
+ *      save_mean/save_invstd: [c] outputs for backward.  running_mean/var updated in place with
+ *      `momentum` (unbiased variance), as F.batch_norm(training=True) does. */
+size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s);
+int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float* save_mean,
+                          float* save_invstd, int32_t n, int32_t c, int32_t s, float eps, float momentum,
+                          int32_t relu, void* ws, size_t ws_bytes);
+/* Backward of the fused op.  y is the forward OUTPUT (its sign is the ReLU mask).  dresidual may be
+ * NULL.  dgamma/dbeta: [c]. */
+int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
+                     const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
+                     float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t relu, void* ws,
+                     size_t ws_bytes);
+
+/* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
+int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);
+int cstp_avgpool_backward(void* stream, const float* dy, float* dx, int32_t rows, int32_t s);
+/* out[c] = sum over n,s of x[n][c][s]  (bias gradient of nn.Linear). */
+int cstp_channel_sum(void* stream, const float* x, float* out, int32_t n, int32_t c, int32_t s, void* ws,
+                     size_t ws_bytes);
+
+/* ---- loss heads ------------------------------------------------------------------------- */
+/* BYOL regression loss r21d_byol.py:346-349: loss[b] = 2 - 2*<x/|x|, y/|y|>, eps 1e-12; x,y [b][f].
+ * backward writes dx only (the target branch is detached, r21d_byol.py:368-369). */
+int cstp_byol_loss_forward(void* stream, const float* x, const float* y, float* loss, int32_t b, int32_t f);
+int cstp_byol_loss_backward(void* stream, const float* x, const float* y, const float* dloss, float* dx,
+                            int32_t b, int32_t f);
+/* nn.CrossEntropyLoss() (mean) main_byol.py:63-68: logits [b][k], labels int64 [b] -> loss[1].
+ * backward: dlogits = dloss[0] * (softmax - onehot) / b. */
+int cstp_cross_entropy_forward(void* stream, const float* logits, const int64_t* labels, float* loss, int32_t b,
+                               int32_t k);
+int cstp_cross_entropy_backward(void* stream, const float* logits, const int64_t* labels, const float* dloss,
+                                float* dlogits, int32_t b, int32_t k);
+/* NT-Xent loss/NTXent.py:46-62 on reps = cat(zjs, zis) [2n][f] (cosine similarity, eps 1e-8).
+ * forward needs ws of cstp_ntxent_workspace_bytes (the 2n x 2n similarity matrix + norms);
+ * backward reuses that ws and writes dreps [2n][f]. */
+size_t cstp_ntxent_workspace_bytes(int32_t two_n, int32_t f);
+int cstp_ntxent_forward(void* stream, const float* reps, float* loss, int32_t two_n, int32_t f, float temperature,
+                        void* ws, size_t ws_bytes);
+int cstp_ntxent_backward(void* stream, const float* reps, const float* dloss, float* dreps, int32_t two_n,
+                         int32_t f, float temperature, void* ws, size_t ws_bytes);
+
+/* ---- per-step utilities over FLAT parameter arenas -------------------------------------- */
+/* EMA r21d_byol.py:331-337: target = target*m + online*(1-m) over n floats. */
+int cstp_ema_update(void* stream, float* target, const float* online, size_t n, double m);
+/* out[0] = sum(g^2) over n floats (for clip_grad_norm_, main_byol.py:88-90); ws >= 8 KiB. */
+int cstp_sumsq(void* stream, const float* g, size_t n, float* out, void* ws, size_t ws_bytes);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0]). */
+int cstp_clip_coef(void* stream, const float* sumsq, float max_norm, float* coef, float* norm_out);
+/* torch.optim.SGD step (main_byol.py:91,228-232; momentum, weight decay, no nesterov, dampening 0):
+ *   g' = g*coef[0] (coef may be NULL); if write_back_grad: g = g';  g' += wd*p;
+ *   buf = first_step ? g' : momentum*buf + g';  p -= lr[0]*buf.   lr is a DEVICE scalar. */
+int cstp_sgd_step(void* stream, float* p, float* g, float* buf, size_t n, const float* lr, float momentum,
+                  float weight_decay, const float* coef, int32_t first_step, int32_t write_back_grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSTP_HIP_H */
