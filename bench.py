@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CSTP pre-training clips/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one full optimisation step of the hot path on one resident synthetic batch:
+4 encoder forwards (2 online + 2 target), EMA, heads, losses, 2 encoder backwards, DDP gradient
+all-reduce (N > 1), clip_grad_norm_(18), SGD -- plus the driver's one device->host read of the
+loss scalars per step, as main_byol.py does for its log line.  One "clip" = one (clip_1, clip_2) pair.
+
+Workload (BASELINE.json configs[1]): R(2+1)D-18, B=16 per GPU, 3x16x112x112 fp32, BYOL + NT-Xent
+(negatives all-gathered across ranks) + overlap-rate heads (loss_weight 0.1 1 1 0 0, ntxent 1);
+weak scaling: per-GPU batch fixed, global batch = 16 N.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the S1-shape spatial conv forward,
+timed with HIP events on its launch stream inside the timed region) and `cpu_baseline` (the CPU
+oracle timed on this host's cores on a bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+DEPTH, B_LOCAL, T, HW = 18, 16, 16, 112
+LOSS_WEIGHT = (0.1, 1.0, 1.0, 0.0, 0.0)
+NTXENT_WEIGHT = 1.0
+
+
+class ConvTimer:
+    """HIP-event timer for the dominant kernel: conv3d forward launches whose geometry matches."""
+
+    def __init__(self, n, c, d, h, w, k, kh):
+        self.key = (n, c, d, h, w, k, kh)
+        self.pairs, self.enabled = [], False
+        self._cur = None
+
+    def match(self, what, desc):
+        return self.enabled and what == "conv3d_forward" and \
+            (desc.n, desc.c, desc.d, desc.h, desc.w, desc.k, desc.kh) == self.key
+
+    def start(self):
+        self._cur = torch.cuda.Event(enable_timing=True)
+        self._cur.record()        # current stream == the stream the C ABI launches on
+
+    def stop(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.append((self._cur, e))
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def cpu_baseline(sample_b=2):
+    """The CPU oracle (stock PyTorch CPU ops; `port`) on a bounded sample of the same workload."""
+    from oracle import r21d_byol_oracle as orc
+    ls = orc.layer_sizes_for_depth(DEPTH)
+    cores = torch.get_num_threads()
+    sd = orc.closed_form_state(ls, torch.float32)
+    x1, x2, labels = orc.closed_form_clips(sample_b, T, HW, torch.float32)
+    t0 = time.time()
+    orc.train_step(sd, {}, x1, x2, labels, ls, 0.01, 0.9, 5e-4, (0.1, 1.0, 1.0, 1.0, 1.0), True)
+    dt = time.time() - t0
+    return {"value": sample_b / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "R(2+1)D-18 full step (fwd+bwd+clip+SGD+EMA), B=%d of %d clip pairs 3x%dx%dx%d, 1 step, %.1f s"
+                      % (sample_b, B_LOCAL, T, HW, HW, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--batch", type=int, default=B_LOCAL)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        world, rank, local_rank = 1, 0, 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from cstp_amd import ops
+    from cstp_amd.ntxent import NTXentLoss
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r21d_byol import R21DBYOL, layer_sizes_for_depth
+    from cstp_amd.synthetic import device_batch
+    from cstp_amd.train import PretrainStep
+
+    torch.manual_seed(1)                       # opts.py:160 default seed; random-init weights
+    model = R21DBYOL(pretrain=True, layer_sizes=layer_sizes_for_depth(args.depth))
+    model.cuda(local_rank)
+    arenas = model.flatten_parameters()
+    model.train()
+    ddp = model
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                        find_unused_parameters=False)
+    opt = FlatSGD(model.parameters(), lr=0.09, momentum=0.9, weight_decay=5e-4, arenas=arenas)
+    ntx = NTXentLoss(device=dev, batch_size=args.batch * world, temperature=0.5, use_cosine_similarity=True)
+    step = PretrainStep(ddp, opt, LOSS_WEIGHT, clip_grad_norm=True, ntxent=ntx, ntxent_weight=NTXENT_WEIGHT)
+    x1, x2, lab = device_batch(args.batch, T, HW, dev, seed=1 + rank)
+
+    timer = ConvTimer(args.batch, 64, T, HW // 2, HW // 2, 144, 3)   # S1: 64 -> 144, 1x3x3 at 16x56x56
+    ops.kernel_timer = timer
+
+    def run(n):
+        for _ in range(n):
+            out = step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+            out.to_host()                        # the driver's per-iteration log read (one sync)
+
+    run(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        clips_s = args.batch * world * args.steps / elapsed
+        k_ms = timer.mean_ms()
+        flops = 2.0 * 144 * 64 * 9 * (args.batch * T * (HW // 2) * (HW // 2))   # algorithmic, per launch
+        ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "pretrain clips/sec (16x112x112)", "value": clips_s, "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "r21d_byol R(2+1)D-%d, B=%d clip pairs/GPU 3x%dx%dx%d, BYOL + NT-Xent(all-gather) + "
+                                   "overlap-rate heads, loss_weight 0.1 1 1 0 0, clip 18, SGD; random-init weights"
+                                   % (args.depth, args.batch, T, HW, HW),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "igemm_k1<5,fwd> spatial conv S1 64->144 1x3x3 @16x56x56 (incl. weight pack)",
+                         "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
+                         "algorithmic_gflop_per_launch": flops / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

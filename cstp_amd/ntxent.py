@@ -1,0 +1,50 @@
+"""NT-Xent contrastive head (mirror of /root/reference/loss/NTXent.py:5-62) with the
+data-parallel extension north_star asks for: negatives all-gathered across ranks on RCCL.
+
+The reference builds ``NTXentLoss(batch_size=opts.batch_size)`` with the GLOBAL batch
+(main_byol.py:191-197), so the only shape-consistent input under DDP is the all-gathered
+embedding matrix.  ``forward(zis, zjs)`` keeps the reference signature; with an initialised
+process group and ``gather=True`` the local [B_local, F] embeddings are gathered to
+[B_global, F] first.  The gather carries gradient only for this rank's slice (every rank
+evaluates the identical global loss), so the caller multiplies the loss by world_size to
+undo DDP's gradient averaging -- ``ddp_scale`` holds that factor.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def all_gather_with_grad(z: torch.Tensor) -> torch.Tensor:
+    """cat over ranks of z (rank-major); gradient flows into the local slice only."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return z
+    parts = [torch.empty_like(z) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, z.detach().contiguous())
+    parts[dist.get_rank()] = z
+    return torch.cat(parts, dim=0)
+
+
+class NTXentLoss(torch.nn.Module):
+    def __init__(self, device, batch_size, temperature, use_cosine_similarity=True, gather=True):
+        super().__init__()
+        if not use_cosine_similarity:
+            raise NotImplementedError("the CSTP driver only builds the cosine-similarity variant (main_byol.py:195)")
+        self.batch_size, self.temperature, self.device, self.gather = batch_size, temperature, device, gather
+
+    @property
+    def ddp_scale(self) -> float:
+        if self.gather and dist.is_available() and dist.is_initialized():
+            return float(dist.get_world_size())
+        return 1.0
+
+    def forward(self, zis, zjs):
+        if self.gather:
+            zis, zjs = all_gather_with_grad(zis), all_gather_with_grad(zjs)
+        if zis.shape[0] != self.batch_size or zjs.shape[0] != self.batch_size:
+            # the reference fails here too: its mask is built for 2*batch_size rows (NTXent.py:23-29,57)
+            raise RuntimeError("NTXentLoss was built for batch_size=%d but got %d embeddings"
+                               % (self.batch_size, zis.shape[0]))
+        return ops.ntxent(torch.cat([zjs, zis], dim=0), self.temperature)

@@ -18,6 +18,10 @@ BN_MOMENTUM = 0.1
 
 _ws_cache = {}
 
+# Optional per-kernel timer installed by bench.py (HIP events on the launch stream around the
+# C-ABI call of matching convolutions); None in normal operation.
+kernel_timer = None
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -82,8 +86,14 @@ class _Conv3d(torch.autograd.Function):
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
         ws = _workspace(x.device, nbytes)
         b = None if bias is None else _req(bias, "conv3d bias")
+        tm = kernel_timer
+        timed = tm is not None and tm.match("conv3d_forward", desc)
+        if timed:
+            tm.start()
         check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(),
                                       ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
+        if timed:
+            tm.stop()
         ctx.save_for_backward(x, w)
         ctx.desc = desc
         ctx.has_bias = bias is not None

@@ -73,7 +73,8 @@ class _BatchNorm(nn.Module):
             raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
         y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps,
                                self.momentum)
-        self.num_batches_tracked += 1
+        if not getattr(self, "_nbt_in_arena", False):
+            self.num_batches_tracked += 1   # else: one add per net per forward, see R21DBYOL.forward
         return y
 
 
@@ -331,7 +332,10 @@ class R21DBYOL(nn.Module):
             for i, m in enumerate(mods):
                 arena[i] = m.num_batches_tracked
                 m.num_batches_tracked = arena[i]
+                m._nbt_in_arena = True
             nbt[name] = arena
+        # forward() calls per step: predictor x2, overlap_spa x1, overlap_tem x1, pb_cls x2, rotate_cls x2
+        nbt["heads_inc"] = torch.tensor([2, 1, 1, 2, 2], dtype=torch.long, device=dev)
         self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
         return self._arenas
 
@@ -369,6 +373,11 @@ class R21DBYOL(nn.Module):
             pred_pb_2 = self.pb_cls(online_feat_2)
             pred_rot_1 = self.rotate_cls(online_feat_1)
             pred_rot_2 = self.rotate_cls(online_feat_2)
+            if self._arenas is not None:   # BN num_batches_tracked: three adds instead of 108
+                nbt = self._arenas["nbt"]
+                nbt["online"] += 2
+                nbt["target"] += 2
+                nbt["heads"] += nbt["heads_inc"]
             # kept for the NT-Xent head and for parity tests (detached views, no extra work)
             self.last_projections = (online_feat_1_proj, online_feat_2_proj)
             return loss.mean(), (pred_spa, pred_tem, pred_pb_1, pred_pb_2, pred_rot_1, pred_rot_2)

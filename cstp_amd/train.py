@@ -1,0 +1,71 @@
+"""One CSTP pre-training step on the GPU: the sequence of main_byol.py:60-91 --
+    model(clip_1, clip_2, o_type) -> 6x CrossEntropy -> loss_weight sum -> zero_grad ->
+    backward (DDP all-reduces gradients on RCCL) -> clip_grad_norm_(18) -> SGD step
+-- with every scalar left on the device (the reference's seven .item() syncs per step are
+deferred to ``StepOutput.to_host()``, called when the driver prints/logs)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+
+CLIP_VALUE = 18  # main_byol.py:89
+
+
+@dataclass
+class StepOutput:
+    loss_total: torch.Tensor
+    loss_byol: torch.Tensor
+    ce: Sequence[torch.Tensor]          # spa, tem, pb_1, pb_2, rot_1, rot_2
+    grad_norm: Optional[torch.Tensor]
+    ntxent: Optional[torch.Tensor]
+    logits: Sequence[torch.Tensor]
+
+    def to_host(self):
+        vals = torch.stack([self.loss_total.detach(), self.loss_byol.detach()] + [c.detach() for c in self.ce]).tolist()
+        return {"loss": vals[0], "loss_byol": vals[1], "loss_pred_spa": vals[2], "loss_pred_tem": vals[3],
+                "loss_pred_pb": (vals[4] + vals[5]) / 2, "loss_pred_rot": (vals[6] + vals[7]) / 2}
+
+
+def normalise_loss_weight(w):
+    if isinstance(w, (int, float)):
+        w = [float(w)]
+    w = list(w)
+    if len(w) != 5:
+        raise ValueError("--loss_weight needs 5 values (byol, spa, tem, pb, rot) for task loss_com, got %r" % (w,))
+    return w
+
+
+class PretrainStep:
+    def __init__(self, model, optimizer, loss_weight, task="loss_com", clip_grad_norm=True, ntxent=None,
+                 ntxent_weight=0.0):
+        self.model, self.optimizer, self.task = model, optimizer, task
+        self.w = normalise_loss_weight(loss_weight)
+        self.clip = bool(clip_grad_norm)
+        self.ntxent, self.ntxent_weight = ntxent, float(ntxent_weight)
+        self._inner = model.module if hasattr(model, "module") else model
+
+    def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
+        w = self.w
+        loss_byol, logits = self.model(clip_1, clip_2, o_type=self.task)
+        loss_byol = loss_byol.mean()
+        ce = [ops.cross_entropy(logits[0], spa), ops.cross_entropy(logits[1], tem), ops.cross_entropy(logits[2], pb),
+              ops.cross_entropy(logits[3], pb), ops.cross_entropy(logits[4], rot_1), ops.cross_entropy(logits[5], rot_2)]
+        loss_total = (w[0] * loss_byol + w[1] * ce[0] + w[2] * ce[1] + w[3] * ce[2] + w[3] * ce[3]
+                      + w[4] * ce[4] + w[4] * ce[5])
+        nt = None
+        objective = loss_total
+        if self.ntxent is not None and self.ntxent_weight != 0.0:
+            z1, z2 = self._inner.last_projections
+            nt = self.ntxent(z1, z2)
+            # every rank holds the same global loss; DDP will average the per-rank gradients
+            objective = loss_total + (self.ntxent_weight * self.ntxent.ddp_scale) * nt
+        self.optimizer.zero_grad()
+        objective.backward()
+        gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None
+        self.optimizer.step()
+        return StepOutput(loss_total.detach(), loss_byol.detach(), [c.detach() for c in ce], gnorm,
+                          None if nt is None else nt.detach(), [l.detach() for l in logits])

@@ -37,11 +37,11 @@ from oracle import r21d_byol_oracle as orc  # noqa: E402  (closed-form fills onl
 
 CONFIGS = {
     # name: (depth, B, T, HW, steps, lr, wd)
-    "d1_small": (1, 4, 8, 56, 3, 0.05, 5e-4),
+    "d1_small": (1, 4, 8, 56, 3, 0.005, 5e-4),
     "d1_cfg1": (1, 4, 16, 112, 1, 0.05, 5e-4),
-    "r18_small": (18, 4, 8, 56, 2, 0.05, 5e-4),
+    "r18_small": (18, 4, 8, 56, 2, 0.005, 5e-4),
     "r18_cfg2": (18, 4, 16, 112, 1, 0.05, 5e-4),
-    "r34_small": (34, 4, 8, 56, 1, 0.05, 5e-4),
+    "r34_small": (34, 8, 8, 64, 1, 0.05, 5e-4),
 }
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 1.0, 1.0)
 

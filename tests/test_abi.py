@@ -1,0 +1,74 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/cstp_hip.h declares;
+the ctypes binding table covers exactly that set.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cstp_hip.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cstp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = header_symbols()
+    assert "cstp_conv3d_forward" in syms and "cstp_bn_forward_train" in syms and "cstp_sgd_step" in syms
+    assert len(syms) >= 20
+
+
+def test_binding_table_matches_header():
+    from cstp_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    from cstp_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__ as entry
+        entry.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), "libcstp_hip.so lacks " + name
+    loaded = _lib.load()
+    assert loaded.cstp_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    """Pure host-side checks of the ABI run before any HIP call."""
+    from cstp_amd import _lib
+    lib = _lib.load()
+    bad = _lib.ConvDesc(0, 3, 4, 8, 8, 8, 1, 3, 3, 1, 1, 1, 0, 1, 1)
+    assert lib.cstp_conv3d_workspace_bytes(ctypes.byref(bad)) == 0
+    ok = _lib.ConvDesc(2, 64, 4, 14, 14, 144, 1, 3, 3, 1, 1, 1, 0, 1, 1)
+    assert lib.cstp_conv3d_workspace_bytes(ctypes.byref(ok)) >= 9 * 64 * 160 * 4
+    rc = lib.cstp_conv3d_forward(None, ctypes.byref(ok), None, None, None, None, None, 0)
+    assert rc != 0 and b"null argument" in lib.cstp_last_error()
+    assert lib.cstp_bn_workspace_bytes(16, 144, 50176) > 0
+    assert lib.cstp_ntxent_workspace_bytes(32, 512) >= (2 * 32 + 2 * 32 * 32) * 4
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from cstp_amd import _lib, ops
+    with pytest.raises(_lib.CstpError):
+        ops.conv3d(torch.zeros(1, 3, 2, 8, 8), torch.zeros(4, 3, 1, 3, 3), None, 1, (0, 1, 1))
+    with pytest.raises(_lib.CstpError):
+        ops.batch_norm_act(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cstp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+    for f in ("main_byol.py", "opts.py"):
+        src = open(os.path.join(ROOT, f)).read()
+        assert "oracle" not in src

@@ -1,0 +1,150 @@
+"""Host-side logic of the drop-in surface (CPU only): flag namespace, LR schedule, meters/logger,
+state-dict contract and init RNG stream of the module mirror, loss-weight handling."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_golden import load, rel
+
+
+def test_opts_surface_matches_reference_flags():
+    from cstp_amd.opts import build_parser, parse_opts
+    o = parse_opts(["--dataset", "synthetic", "--batch_size", "128", "--sample_duration", "16", "--model_name", "r21d_byol",
+                    "--model_depth", "18", "--n_epochs", "300", "--learning_rate", "0.09", "--weight_decay", "5e-4",
+                    "--sample_size", "112", "--n_workers", "6", "--task", "loss_com", "--optimizer", "sgd",
+                    "--loss_weight", "0.1", "1", "1", "1", "1", "--local_rank", "3"])
+    assert o.batch_size == 128 and o.model_name == "r21d_byol" and o.loss_weight == [0.1, 1, 1, 1, 1]
+    assert o.local_rank == 3 and o.dist_backend == "nccl" and o.dist_url == "env://" and o.manual_seed == 1
+    assert o.temperature == 0.5 and o.sync_bn == 1 and o.clip_grad_norm == 1 and o.momentum == 0.9
+    # every flag of the reference's opts.py (names/defaults read from /root/reference/opts.py:4-245)
+    ref_flags = """frame_dir annotation_path dataset split modality input_channels n_classes n_finetune_classes model_name
+        model_depth resnet_shortcut resnext_cardinality ft_begin_index sample_size sample_duration batch_size n_workers
+        pretrained_path test_md_path resume_md_path learning_rate momentum dampening weight_decay nesterov optimizer
+        lr_patience n_epochs result_path log manual_seed random_seed cuda highest_val device tau alpha input_h input_w
+        temperature task temp_transform lr_decay local_rank rank dist_url dist_backend world_size nprocs distributed
+        sync_bn clip_grad_norm split_path pb_rate transform_mode input_size output_feat norm_method max_iter loss_weight
+        t_ft_task sc_type lmdb_path""".split()
+    assert len(ref_flags) == 63
+    have = {a.dest for a in build_parser()._actions}
+    assert not [f for f in ref_flags if f not in have]
+    d = parse_opts([])
+    assert d.model_depth == 101 and d.batch_size == 32 and d.learning_rate == 3e-4 and d.loss_weight == 1.0
+    assert d.ntxent_weight == 0.0   # the reference never adds NT-Xent to loss_total
+
+
+def test_local_rank_from_env(monkeypatch):
+    from cstp_amd.opts import parse_opts
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert parse_opts([]).local_rank == 5
+    assert parse_opts(["--local_rank", "2"]).local_rank == 2
+
+
+def test_scheduler_matches_reference_known_answers():
+    from cstp_amd.scheduler import CosineAnnealingWarmupRestarts
+    g = load("misc")
+    for n_epochs, lr in ((300, 0.09), (10, 0.03)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr, momentum=0.9)
+        sch = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=n_epochs, cycle_mult=1.0, max_lr=lr, min_lr=0.00001,
+                                            warmup_steps=0.5 * n_epochs, gamma=0.5)
+        lrs = []
+        for _ in range(n_epochs):
+            lrs.append(opt.param_groups[-1]["lr"])
+            sch.step()
+        assert rel(lrs, g["lrs.%d.%g" % (n_epochs, lr)]) < 1e-12
+    with pytest.raises(AssertionError):
+        CosineAnnealingWarmupRestarts(opt, first_cycle_steps=4, warmup_steps=4)
+
+
+def test_meters_and_logger(tmp_path):
+    from cstp_amd.utils import LOG_COLUMNS, AverageMeter, Logger
+    m = AverageMeter()
+    m.update(2.0, 4)
+    m.update(4.0, 4)
+    assert m.val == 4.0 and m.avg == 3.0 and m.count == 8
+    path = tmp_path / "log.tsv"
+    lg = Logger(str(path), LOG_COLUMNS, overlay=True)
+    lg.log({c: i for i, c in enumerate(LOG_COLUMNS)})
+    with pytest.raises(AssertionError):
+        lg.log({"epoch": 1})
+    lg.close()
+    rows = path.read_text().strip().split("\n")
+    assert rows[0].split("\t") == ["epoch", "loss", "loss_byol", "loss_pred_spa", "loss_pred_tem", "loss_pred_pb",
+                                   "loss_pred_rot", "acc", "lr"]
+    assert rows[1].split("\t")[0] == "0"
+
+
+@pytest.mark.parametrize("name", ["d1_small", "r18_small", "r34_small"])
+def test_module_mirror_state_dict_contract(name):
+    """Same state-dict keys, order and shapes as the reference module (golden state_keys/param_keys)."""
+    from cstp_amd.r21d_byol import R21DBYOL, layer_sizes_for_depth
+    from oracle import r21d_byol_oracle as orc
+    g = load(name)
+    depth = int(g["meta"][0])
+    torch.manual_seed(0)
+    m = R21DBYOL(pretrain=True, layer_sizes=layer_sizes_for_depth(depth))
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    assert [k for k, _ in m.named_parameters()] == [str(k) for k in g["param_keys"]]
+    spec = {k: tuple(s) for k, s, _ in orc.model_spec(orc.layer_sizes_for_depth(depth))}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == spec
+    assert all(not p.requires_grad for p in m.target_net.parameters())
+    assert all(p.requires_grad for p in m.online_net.parameters())
+
+
+def test_module_mirror_init_matches_reference_rng_stream():
+    """R21DBYOL(pretrain=True) under torch.manual_seed(1) (opts.py:160): per-tensor checksums equal the
+    reference's -- same construction order, default initialisers and Glorot overwrite (r21d_byol.py:301-329)."""
+    from cstp_amd.r21d_byol import R21DBYOL
+    g = load("misc")
+    torch.manual_seed(1)
+    m = R21DBYOL(pretrain=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["init.keys"]]
+    ours = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    assert np.abs(ours - g["init.cs"]).max() < 1e-9
+    # target initialised independently of online, BN gamma ~ U(+-sqrt(6/C)) not 1
+    assert not torch.equal(sd["online_net.conv1.spatial_conv.weight"], sd["target_net.conv1.spatial_conv.weight"])
+    assert float(sd["online_net.bn1.weight"].abs().max()) <= math.sqrt(6 / 64) + 1e-6
+
+
+def test_model_interface_errors():
+    from cstp_amd.model import generate_model
+    from cstp_amd.opts import parse_opts
+    from cstp_amd.r21d_byol import R21DBYOL, layer_sizes_for_depth
+    with pytest.raises(ValueError):
+        layer_sizes_for_depth(50)
+    with pytest.raises(NotImplementedError):
+        R21DBYOL(pretrain=False, num_classes=101, cls_bn=True)
+    o = parse_opts(["--model_name", "c3d_byol", "--task", "loss_com"])
+    with pytest.raises(ValueError):
+        generate_model(o)
+    o = parse_opts(["--model_name", "r21d_byol", "--task", "ft_all"])
+    with pytest.raises(NotImplementedError):
+        generate_model(o)
+    if not torch.cuda.is_available():
+        o = parse_opts(["--model_name", "r21d_byol", "--task", "loss_com", "--model_depth", "1"])
+        with pytest.raises(RuntimeError):
+            generate_model(o)
+    m = R21DBYOL(pretrain=True)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1), torch.zeros(1), o_type="nonsense")
+
+
+def test_loss_weight_normalisation():
+    from cstp_amd.train import normalise_loss_weight
+    assert normalise_loss_weight([0.1, 1, 1, 1, 1]) == [0.1, 1, 1, 1, 1]
+    with pytest.raises(ValueError):
+        normalise_loss_weight(1.0)      # the opts default is a bare float: loss_com needs five weights
+
+
+def test_synthetic_dataset_label_ranges():
+    from cstp_amd.synthetic import SyntheticClips
+    ds = SyntheticClips(length=8, sample_duration=4, sample_size=16, seed=1)
+    (c1, c2), (spa, tem, pb, (r1, r2)) = ds[3]
+    assert c1.shape == (3, 4, 16, 16) and c1.dtype == torch.float32 and float(c1.abs().max()) <= 1.0
+    assert 0 <= spa < 5 and 0 <= tem < 5 and 0 <= pb < 4 and 0 <= r1 < 4 and 0 <= r2 < 4
+    (d1, _), _ = ds[3]
+    assert torch.equal(c1, d1) and not torch.equal(c1, c2)

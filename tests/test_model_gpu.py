@@ -1,0 +1,193 @@
+"""End-to-end parity of the HIP path (cstp_amd, through the C ABI) on a real MI355X:
+  * against golden vectors captured from the reference run in fp64 (tests/golden/*.npz);
+  * against the CPU oracle on seeded ragged inputs (odd T/H/W, batch 3);
+  * size-independent properties at BASELINE.json's full single-GPU size (R18, B=16, 16x112x112).
+The training loop below reads like the reference's main_byol.py:60-91."""
+import numpy as np
+import pytest
+import torch
+
+from test_oracle_golden import OUT_SCALE, STATE_TOLS, TOLS, cs_err, load, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(layer_sizes, sd=None):
+    from cstp_amd.r21d_byol import R21DBYOL
+    model = R21DBYOL(pretrain=True, layer_sizes=layer_sizes)
+    if sd is not None:
+        missing = model.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    model.cuda()
+    model.flatten_parameters()
+    model.train()
+    return model
+
+
+def one_step(model, opt, x1, x2, labels, w, clip=True):
+    """main_byol.py:60-91 on the HIP path; returns scalars + pre-clip per-parameter gradient norms."""
+    from cstp_amd import ops
+    loss_byol, logits = model(x1, x2, o_type="loss_com")
+    loss_byol = loss_byol.mean()
+    ce = [ops.cross_entropy(logits[0], labels["spa"]), ops.cross_entropy(logits[1], labels["tem"]),
+          ops.cross_entropy(logits[2], labels["pb"]), ops.cross_entropy(logits[3], labels["pb"]),
+          ops.cross_entropy(logits[4], labels["rot1"]), ops.cross_entropy(logits[5], labels["rot2"])]
+    total = (w[0] * loss_byol + w[1] * ce[0] + w[2] * ce[1] + w[3] * ce[2] + w[3] * ce[3] + w[4] * ce[4] + w[4] * ce[5])
+    opt.zero_grad()
+    total.backward()
+    gnorms = {k: float(p.grad.norm()) for k, p in model.named_parameters() if p.requires_grad}
+    gnorm = opt.clip_grad_norm_(18) if clip else None
+    opt.step()
+    return {"loss_byol": float(loss_byol), "loss_total": float(total), "ce": [float(c) for c in ce],
+            "logits": torch.stack([l.detach() for l in logits]).cpu().numpy(), "grad_norm": float(gnorm),
+            "grad_norms": gnorms}
+
+
+def checksums(model, keys):
+    sd = model.state_dict()
+    return np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+
+
+def momentum_checksums(opt):
+    sd = opt.state_dict()["state"]
+    n = len(opt.param_groups[0]["params"])
+    return np.array([[float(sd[i]["momentum_buffer"].double().sum()), float(sd[i]["momentum_buffer"].double().abs().sum())]
+                     if i in sd else [0.0, 0.0] for i in range(n)])
+
+
+@pytest.mark.parametrize("name", ["d1_small", "r18_small", "r34_small", "d1_cfg1", "r18_cfg2"])
+def test_hip_path_matches_reference_golden(name):
+    from cstp_amd.optim import FlatSGD
+    from oracle import r21d_byol_oracle as orc
+    g = load(name)
+    depth, b, t, hw, nsteps = [int(v) for v in g["meta"]]
+    ls = orc.layer_sizes_for_depth(depth)
+    sd = orc.closed_form_state(ls, torch.float32)
+    x1, x2, labels = orc.closed_form_clips(b, t, hw, torch.float32)
+    x1, x2 = x1.cuda(), x2.cuda()
+    labels = {k: v.cuda() for k, v in labels.items()}
+    keys = [str(k) for k in g["state_keys"]]
+    pkeys = [str(k) for k in g["param_keys"]]
+
+    # ---- forward internals (reference forward order, r21d_byol.py:359-366) on a fresh model
+    model = build_model(ls, sd)
+    assert list(model.state_dict().keys()) == keys          # state-dict contract
+    assert [k for k, _ in model.named_parameters()] == pkeys
+    with torch.no_grad():
+        f1, z1 = model.online_net(x1)
+        f2, z2 = model.online_net(x2)
+        p1, p2 = model.predictor(z1), model.predictor(z2)
+        model._update_target_net()
+        _, t1 = model.target_net(x1)
+        _, t2 = model.target_net(x2)
+    for k, v in (("feat_1", f1), ("feat_2", f2), ("proj_1", z1), ("proj_2", z2), ("pred_1", p1), ("pred_2", p2),
+                 ("tproj_1", t1), ("tproj_2", t2)):
+        assert rel(v.cpu().numpy(), g["fwd." + k]) < TOLS[1][0] * OUT_SCALE.get(name, 1.0), k
+    from cstp_amd import ops
+    nt = ops.ntxent(torch.cat([z2, z1], 0), 0.5)
+    assert rel(float(nt), g["fwd.ntxent"]) < TOLS[1][0] * OUT_SCALE.get(name, 1.0)
+
+    # ---- optimisation steps
+    model = build_model(ls, sd)
+    opt = FlatSGD(model.parameters(), lr=float(g["lr"]), momentum=0.9, weight_decay=float(g["wd"]),
+                  arenas=model.flatten_parameters())
+    for s in range(1, nsteps + 1):
+        tol, gtol = TOLS[s]
+        tol *= OUT_SCALE.get(name, 1.0)
+        pre = "s%d." % s
+        out = one_step(model, opt, x1, x2, labels, tuple(g["loss_weight"]))
+        assert rel(out["loss_byol"], g[pre + "loss_byol"]) < tol
+        assert rel(out["loss_total"], g[pre + "loss_total"]) < tol
+        assert rel(out["ce"], g[pre + "ce"]) < tol
+        assert rel(out["logits"], g[pre + "logits"]) < tol
+        assert rel(out["grad_norm"], g[pre + "grad_norm"]) < gtol
+        gn = np.array([out["grad_norms"].get(k, -1.0) for k in pkeys])
+        assert rel(gn, g[pre + "grad_norms"]) < gtol
+        assert cs_err(checksums(model, keys), g[pre + "state_cs"]) < STATE_TOLS[s]
+        ref_m = g[pre + "mom_cs"]
+        trainable = [i for i, k in enumerate(pkeys) if not k.startswith("target_net.")]
+        assert cs_err(momentum_checksums(opt), ref_m[trainable]) < gtol
+    # BN counters: online/target nets see two forwards per step (r21d_byol.py:359-366)
+    msd = model.state_dict()
+    assert int(msd["online_net.bn1.num_batches_tracked"]) == 2 * nsteps
+    assert int(msd["target_net.bn1.num_batches_tracked"]) == 2 * nsteps
+    assert int(msd["overlap_spa.1.num_batches_tracked"]) == nsteps
+    assert int(msd["pb_cls.1.num_batches_tracked"]) == 2 * nsteps
+
+
+@pytest.mark.parametrize("depth,b,t,hw", [(1, 3, 6, 36), (18, 2, 5, 28)])
+def test_hip_path_matches_oracle_on_ragged_inputs(depth, b, t, hw):
+    """Odd temporal/spatial sizes (stride-2 layers see odd extents) and a batch of 3/2, seeded."""
+    from cstp_amd.optim import FlatSGD
+    from oracle import r21d_byol_oracle as orc
+    ls = orc.layer_sizes_for_depth(depth)
+    sd = orc.closed_form_state(ls, torch.float32)
+    x1, x2, labels = orc.closed_form_clips(b, t, hw, torch.float32, seed_phase=5)
+    w = (0.1, 1.0, 1.0, 1.0, 1.0)
+    mom = {}
+    osd = {k: v.clone() for k, v in sd.items()}
+    info = orc.train_step(osd, mom, x1, x2, labels, ls, 0.05, 0.9, 5e-4, w, True)
+    model = build_model(ls, sd)
+    opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=model.flatten_parameters())
+    out = one_step(model, opt, x1.cuda(), x2.cuda(), {k: v.cuda() for k, v in labels.items()}, w)
+    tol, gtol = 2e-4, 2e-2   # fp32 vs fp32 (two different summation orders)
+    assert rel(out["loss_byol"], float(info["loss_byol"])) < tol
+    assert rel(out["loss_total"], float(info["loss_total"])) < tol
+    assert rel(out["logits"], torch.stack(info["logits"]).numpy()) < 5 * tol
+    assert rel(out["grad_norm"], float(info["grad_norm"])) < gtol
+    pk = [k for k in out["grad_norms"]]
+    assert rel(np.array([out["grad_norms"][k] for k in pk]), np.array([float(info["grads"][k].norm()) for k in pk])) < gtol
+    msd = model.state_dict()
+    for k in ("online_net.conv1.bn.running_mean", "online_net.conv5.block1.bn2.running_var", "target_net.bn1.running_var",
+              "target_net.conv2.block1.conv1.spatial_conv.weight", "predictor.net.1.running_mean"):
+        assert rel(msd[k].cpu().numpy(), osd[k].detach().numpy()) < 5 * tol, k
+
+
+def test_full_size_properties_r18_b16():
+    """BASELINE.json cfg2 size (R(2+1)D-18, B=16, 3x16x112x112): properties that need no oracle run."""
+    from cstp_amd import ops
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.synthetic import device_batch
+    torch.manual_seed(1)
+    model = build_model((2, 2, 2, 2))
+    a = model.flatten_parameters()
+    x1, x2, labels = device_batch(16, 16, 112, torch.device("cuda"), seed=1)
+    opt = FlatSGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4, arenas=a)
+    t_before = a["target"].clone()
+    q_before = a["param"][:a["n_encoder"]].clone()
+    p_before = a["param"].clone()
+    out = one_step(model, opt, x1, x2, labels, (0.1, 1, 1, 1, 1))
+    # (1) everything finite, BYOL loss = sum of two (2 - 2cos) terms in [0, 8]
+    assert np.isfinite(out["loss_total"]) and 0.0 <= out["loss_byol"] <= 8.0
+    assert all(np.isfinite(v) for v in out["grad_norms"].values())
+    # (2) EMA is linear in the pre-step online weights and runs BEFORE the optimiser step
+    expect = t_before * 0.996 + q_before * (1.0 - 0.996)
+    assert rel(a["target"], expect) < 1e-6
+    # (3) SGD first step: p_new = p - lr * (clip * g + wd * p); .grad holds the clipped gradient
+    coef = min(1.0, 18.0 / (out["grad_norm"] + 1e-6))
+    clipped = a["grad"]
+    total_norm = float(clipped.double().norm())
+    assert abs(total_norm - out["grad_norm"] * coef) / (out["grad_norm"] * coef) < 1e-4
+    assert rel(a["param"], p_before - 0.01 * (clipped + 5e-4 * p_before)) < 1e-5
+    # (4) train-mode BN output statistics: per-channel mean = beta, var = gamma^2 (up to eps)
+    y = torch.randn(16, 64, 16, 56, 56, device="cuda") * 3 + 1
+    gamma = torch.rand(64, device="cuda") + 0.5
+    beta = torch.randn(64, device="cuda")
+    z = ops.batch_norm_act(y, gamma, beta)
+    assert rel(z.mean(dim=(0, 2, 3, 4)), beta) < 1e-4
+    assert rel(z.var(dim=(0, 2, 3, 4), unbiased=False), gamma * gamma) < 1e-3
+    # (5) conv linearity at the S1 shape: conv(a*x1 + x2) == a*conv(x1) + conv(x2)
+    wt = torch.randn(144, 64, 1, 3, 3, device="cuda") * 0.05
+    u, v = torch.randn(2, 16, 64, 16, 56, 56, device="cuda").unbind(0)
+    lhs = ops.conv3d(1.7 * u + v, wt, None, 1, (0, 1, 1))
+    rhs = 1.7 * ops.conv3d(u, wt, None, 1, (0, 1, 1)) + ops.conv3d(v, wt, None, 1, (0, 1, 1))
+    assert rel(lhs, rhs) < 1e-5
+    # (6) <dy, conv(x)> == <conv_dgrad(dy), x> == <conv_wgrad(x, dy), w>  (adjoint identities)
+    u.requires_grad_(True)
+    wt.requires_grad_(True)
+    yy = ops.conv3d(u, wt, None, 1, (0, 1, 1))
+    dy = torch.randn_like(yy)
+    yy.backward(dy)
+    lhs = float((dy.double() * yy.detach().double()).sum())
+    assert abs(float((u.grad.double() * u.detach().double()).sum()) - lhs) / abs(lhs) < 1e-4
+    assert abs(float((wt.grad.double() * wt.detach().double()).sum()) - lhs) / abs(lhs) < 1e-4
