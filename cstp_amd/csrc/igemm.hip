@@ -181,21 +181,26 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int kr = krow0 + 2 * r;
-      float v = 0.f;
+      // Loads are UNCONDITIONAL (address clamped to element 0 when masked) and the zero is selected
+      // afterwards: a branch around each load makes hipcc wait vmcnt(0) per element (serialised).
+      bool ok;
+      size_t off;
       if (STRADDLE) {
         const int k = kbase + kr;
-        if (k < g.Ktot && nvalid) {
-          const int tp = k / g.Cp, c = k - tp * g.Cp;
-          const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
-          const int id = npd * g.st - g.pt + dt, ih = nph * g.sh - g.ph + dh, iw = npw * g.sw - g.pw + dw;
-          if (c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws)
-            v = src[src_b + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw];
-        }
+        const int kc = k < g.Ktot ? k : 0;
+        const int tp = kc / g.Cp, c = kc - tp * g.Cp;
+        const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+        const int id = npd * g.st - g.pt + dt, ih = nph * g.sh - g.ph + dh, iw = npw * g.sw - g.pw + dw;
+        ok = nvalid && k < g.Ktot && c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
+             (unsigned)iw < (unsigned)g.Ws;
+        off = src_b + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw;
       } else {
         const int c = c0 + kr;
-        if (tvalid && c < g.Cs) v = src[src_b + (size_t)c * DHWs + toff];
+        ok = tvalid && c < g.Cs;
+        off = src_b + (size_t)c * DHWs + toff;
       }
-      rb[r] = v;
+      const float v = src[ok ? off : 0];
+      rb[r] = ok ? v : 0.f;
     }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
@@ -316,13 +321,16 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     // A tile: dy rows m = wave + 4r
     {
       const size_t ab = (size_t)b * g.M * S + sp;
+      float va[BM / 4];
 #pragma unroll
-      for (int r = 0; r < BM / 4; ++r) {
+      for (int r = 0; r < BM / 4; ++r) {      // unconditional clamped loads (see K1), batched by the compiler
         const int m = wave + 4 * r;
-        float v = 0.f;
-        if (nvalid && (m0 + m) < g.M) v = dy[ab + (size_t)(m0 + m) * S];
-        As[m * LD + lane] = v;
+        const bool ok = nvalid && (m0 + m) < g.M;
+        const float v = dy[ok ? ab + (size_t)(m0 + m) * S : 0];
+        va[r] = ok ? v : 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < BM / 4; ++r) As[(wave + 4 * r) * LD + lane] = va[r];
     }
     // B tile: this wave gathers exactly the 32 columns it consumes
     if (wave_active) {
@@ -332,26 +340,28 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
         const bool v0 = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
                         (unsigned)iw < (unsigned)g.Ws;
         const int toff = id * HWs + ih * g.Ws + iw;
+        float vb[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
           const int c = cw0 + r;
-          float v = 0.f;
-          if (v0 && c < g.Cs) v = x[xb + (size_t)c * DHWs + toff];
-          Bs[(wave * 32 + r) * LD + lane] = v;
+          const bool ok = v0 && c < g.Cs;
+          const float v = x[ok ? xb + (size_t)c * DHWs + toff : 0];
+          vb[r] = ok ? v : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) Bs[(wave * 32 + r) * LD + lane] = vb[r];
       } else {
 #pragma unroll 4
         for (int r = 0; r < 32; ++r) {
           const int j = jw0 + r;
-          float v = 0.f;
-          if (nvalid && j < Jtot) {
-            const int tp = j / g.Cp, c = j - tp * g.Cp;
-            const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
-            const int id = od * g.st - g.pt + dt, ih = oh * g.sh - g.ph + dh, iw = ow * g.sw - g.pw + dw;
-            if (c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws)
-              v = x[xb + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw];
-          }
-          Bs[(wave * 32 + r) * LD + lane] = v;
+          const int jc = j < Jtot ? j : 0;
+          const int tp = jc / g.Cp, c = jc - tp * g.Cp;
+          const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+          const int id = od * g.st - g.pt + dt, ih = oh * g.sh - g.ph + dh, iw = ow * g.sw - g.pw + dw;
+          const bool ok = nvalid && j < Jtot && c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
+                          (unsigned)iw < (unsigned)g.Ws;
+          const float v = x[ok ? xb + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw : 0];
+          Bs[(wave * 32 + r) * LD + lane] = ok ? v : 0.f;
         }
       }
     }
