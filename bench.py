@@ -121,7 +121,8 @@ def main():
     step = PretrainStep(ddp, opt, LOSS_WEIGHT, clip_grad_norm=True, ntxent=ntx, ntxent_weight=NTXENT_WEIGHT)
     x1, x2, lab = device_batch(args.batch, T, HW, dev, seed=1 + rank)
 
-    timer = ConvTimer(args.batch, 64, T, HW // 2, HW // 2, 144, 3)   # S1: 64 -> 144, 1x3x3 at 16x56x56
+    # S1: 64 -> 144, 1x3x3 at 16x56x56; both views of the pair share one launch (batch 2B, two BN groups)
+    timer = ConvTimer(2 * args.batch, 64, T, HW // 2, HW // 2, 144, 3)
     ops.kernel_timer = timer
 
     def run(n):
@@ -150,7 +151,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         clips_s = args.batch * world * args.steps / elapsed
         k_ms = timer.mean_ms()
-        flops = 2.0 * 144 * 64 * 9 * (args.batch * T * (HW // 2) * (HW // 2))   # algorithmic, per launch
+        flops = 2.0 * 144 * 64 * 9 * (2 * args.batch * T * (HW // 2) * (HW // 2))   # algorithmic, per launch
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         line = {
             "metric": "pretrain clips/sec (16x112x112)", "value": clips_s, "unit": "clips/s", "n_gpus": world,
@@ -162,7 +163,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "igemm_k1<5,fwd> spatial conv S1 64->144 1x3x3 @16x56x56 (incl. weight pack)",
+                         "kernel": "igemm_k1<5,fwd> spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
                          "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
                          "algorithmic_gflop_per_launch": flops / 1e9},
         }

@@ -5,6 +5,12 @@
 //
 // Layout: x[n][c][s], s = D*H*W contiguous.  For s == 1 (BatchNorm1d over [B][F]) a dedicated
 // single-launch kernel keeps lanes along the contiguous feature axis.
+//
+// GROUPS: the batch may hold `groups` independent BN calls back to back (n = groups * n_per_group);
+// statistics are per (group, channel) and the running stats are updated group after group, exactly
+// as `groups` successive F.batch_norm calls would.  The model uses groups = 2 to push both views
+// of a clip pair through one launch sequence (same weights, per-view statistics -- identical maths
+// to the reference's two calls, r21d_byol.py:359-360, with half the launches and twice the grid).
 #include "common.h"
 
 namespace cstp {
@@ -21,14 +27,15 @@ static inline int bn_nsplit(int n, int c) {
 template <int MODE, bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                 const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int n,
+                 const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int npg,
                  int c, int s, int nsplit, int relu) {
   __shared__ double sm[16];
-  const int ch = blockIdx.x, j = blockIdx.y;
+  const int ch = blockIdx.x, grp = blockIdx.y / nsplit, j = blockIdx.y - grp * nsplit;
   double a0 = 0.0, a1 = 0.0;
   float mu = 0.f, is = 0.f;
-  if (MODE == 1) { mu = mean[ch]; is = invstd[ch]; }
-  for (int row = j; row < n; row += nsplit) {
+  if (MODE == 1) { mu = mean[grp * c + ch]; is = invstd[grp * c + ch]; }
+  for (int rr = j; rr < npg; rr += nsplit) {
+    const int row = grp * npg + rr;
     const size_t base = ((size_t)row * c + ch) * s;
     if (VEC4) {
       const float4* xp = reinterpret_cast<const float4*>(x + base);
@@ -68,41 +75,53 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
   a0 = block_sum(a0, sm);
   a1 = block_sum(a1, sm);
   if (threadIdx.x == 0) {
-    part[((size_t)ch * nsplit + j) * 2 + 0] = a0;
-    part[((size_t)ch * nsplit + j) * 2 + 1] = a1;
+    part[((size_t)ch * gridDim.y + blockIdx.y) * 2 + 0] = a0;
+    part[((size_t)ch * gridDim.y + blockIdx.y) * 2 + 1] = a1;
   }
 }
 
 // ---- stage 2 (forward): mean / invstd / running stats ------------------------------------------
 __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
-                                       float* __restrict__ running_var, int c, int nsplit, double count, float eps,
-                                       float momentum) {
+                                       float* __restrict__ running_var, int c, int groups, int nsplit, double count,
+                                       float eps, float momentum) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int j = 0; j < nsplit; ++j) { s0 += part[((size_t)ch * nsplit + j) * 2]; s1 += part[((size_t)ch * nsplit + j) * 2 + 1]; }
-  const double mu = s0 / count;
-  double var = s1 / count - mu * mu;
-  if (var < 0.0) var = 0.0;
-  save_mean[ch] = (float)mu;
-  save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean != nullptr) {
+  float rm = 0.f, rv = 0.f;
+  if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    save_mean[g * c + ch] = (float)mu;
+    save_invstd[g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
-    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+    rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
+    rv = (float)((1.0 - momentum) * rv + momentum * unb);
   }
+  if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
 }
 
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int c, int nsplit) {
+                                       float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
+                                       int nsplit) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int j = 0; j < nsplit; ++j) { s0 += part[((size_t)ch * nsplit + j) * 2]; s1 += part[((size_t)ch * nsplit + j) * 2 + 1]; }
-  dbeta[ch] = (float)s0;
-  dgamma[ch] = (float)s1;
+  double t0 = 0.0, t1 = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+    gsum[(g * c + ch) * 2 + 0] = (float)s0;     // per-group sum(g), sum(g*xhat) for the dx pass
+    gsum[(g * c + ch) * 2 + 1] = (float)s1;
+    t0 += s0; t1 += s1;
+  }
+  dbeta[ch] = (float)t0;                        // the affine parameters are shared by the groups
+  dgamma[ch] = (float)t1;
 }
 
 // ---- stage 3 (forward): y = act((x-mean)*invstd*gamma + beta + residual) -----------------------
@@ -110,14 +129,16 @@ template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                    const float* __restrict__ invstd, size_t total, int c, int s, int relu) {
+                    const float* __restrict__ invstd, size_t total, int c, int s, int npg, int relu) {
   constexpr int W = VEC4 ? 4 : 1;
   const size_t nvec = total / W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const size_t e = i * W;
-    const int ch = (int)((e / s) % c);
-    const float sc = invstd[ch] * gamma[ch];
-    const float sh = beta[ch] - mean[ch] * sc;
+    const size_t row = e / s;
+    const int ch = (int)(row % c);
+    const int gc = (int)(row / c) / npg * c + ch;
+    const float sc = invstd[gc] * gamma[ch];
+    const float sh = beta[ch] - mean[gc] * sc;
     if (VEC4) {
       float4 v = reinterpret_cast<const float4*>(x)[i];
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
@@ -141,16 +162,18 @@ template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx,
-                    float* __restrict__ dres, size_t total, int c, int s, float inv_count, int relu) {
+                    const float* __restrict__ gsum, float* __restrict__ dx,
+                    float* __restrict__ dres, size_t total, int c, int s, int npg, float inv_count, int relu) {
   constexpr int W = VEC4 ? 4 : 1;
   const size_t nvec = total / W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const size_t e = i * W;
-    const int ch = (int)((e / s) % c);
-    const float mu = mean[ch], is = invstd[ch];
+    const size_t row = e / s;
+    const int ch = (int)(row % c);
+    const int gc = (int)(row / c) / npg * c + ch;
+    const float mu = mean[gc], is = invstd[gc];
     const float k = gamma[ch] * is;
-    const float mb = dbeta[ch] * inv_count, mg = dgamma[ch] * inv_count;
+    const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
     if (VEC4) {
       const float4 v = reinterpret_cast<const float4*>(x)[i];
       float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -179,55 +202,66 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
 __global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 float* __restrict__ running_mean, float* __restrict__ running_var,
-                                float* __restrict__ save_mean, float* __restrict__ save_invstd, int n, int c, float eps,
-                                float momentum, int relu) {
+                                float* __restrict__ save_mean, float* __restrict__ save_invstd, int npg, int groups, int c,
+                                float eps, float momentum, int relu) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < n; ++r) { const double v = x[(size_t)r * c + ch]; s0 += v; s1 += v * v; }
-  const double mu = s0 / n;
-  double var = s1 / n - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  save_mean[ch] = (float)mu;
-  save_invstd[ch] = is;
-  if (running_mean != nullptr) {
-    const double unb = n > 1 ? var * n / (n - 1.0) : var;
-    running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mu);
-    running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+  float rm = 0.f, rv = 0.f;
+  if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  const float ga = gamma[ch], be = beta[ch];
+  for (int g = 0; g < groups; ++g) {
+    const size_t r0 = (size_t)g * npg;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < npg; ++r) { const double v = x[(r0 + r) * c + ch]; s0 += v; s1 += v * v; }
+    const double mu = s0 / npg;
+    double var = s1 / npg - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[g * c + ch] = (float)mu;
+    save_invstd[g * c + ch] = is;
+    const double unb = npg > 1 ? var * npg / (npg - 1.0) : var;
+    rm = (float)((1.0 - momentum) * rm + momentum * mu);
+    rv = (float)((1.0 - momentum) * rv + momentum * unb);
+    const float sc = is * ga, sh = be - (float)mu * sc;
+    for (int r = 0; r < npg; ++r) {
+      float v = x[(r0 + r) * c + ch] * sc + sh;
+      if (res != nullptr) v += res[(r0 + r) * c + ch];
+      if (relu) v = fmaxf(v, 0.f);
+      y[(r0 + r) * c + ch] = v;
+    }
   }
-  const float sc = is * gamma[ch], sh = beta[ch] - (float)mu * sc;
-  for (int r = 0; r < n; ++r) {
-    float v = x[(size_t)r * c + ch] * sc + sh;
-    if (res != nullptr) v += res[(size_t)r * c + ch];
-    if (relu) v = fmaxf(v, 0.f);
-    y[(size_t)r * c + ch] = v;
-  }
+  if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
 }
 
 __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, float* __restrict__ dx, float* __restrict__ dres,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, int n, int c, int relu) {
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int npg, int groups, int c, int relu) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  const float mu = mean[ch], is = invstd[ch];
-  double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < n; ++r) {
-    float g = dy[(size_t)r * c + ch];
-    if (relu && !(y[(size_t)r * c + ch] > 0.f)) g = 0.f;
-    s0 += (double)g;
-    s1 += (double)(g * ((x[(size_t)r * c + ch] - mu) * is));
+  double t0 = 0.0, t1 = 0.0;
+  const float ga = gamma[ch];
+  for (int g = 0; g < groups; ++g) {
+    const size_t r0 = (size_t)g * npg;
+    const float mu = mean[g * c + ch], is = invstd[g * c + ch];
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < npg; ++r) {
+      float gr = dy[(r0 + r) * c + ch];
+      if (relu && !(y[(r0 + r) * c + ch] > 0.f)) gr = 0.f;
+      s0 += (double)gr;
+      s1 += (double)(gr * ((x[(r0 + r) * c + ch] - mu) * is));
+    }
+    t0 += s0; t1 += s1;
+    const float k = ga * is, mb = (float)s0 / npg, mg = (float)s1 / npg;
+    for (int r = 0; r < npg; ++r) {
+      float gr = dy[(r0 + r) * c + ch];
+      if (relu && !(y[(r0 + r) * c + ch] > 0.f)) gr = 0.f;
+      if (dres != nullptr) dres[(r0 + r) * c + ch] = gr;
+      dx[(r0 + r) * c + ch] = k * (gr - mb - (x[(r0 + r) * c + ch] - mu) * is * mg);
+    }
   }
-  dbeta[ch] = (float)s0;
-  dgamma[ch] = (float)s1;
-  const float k = gamma[ch] * is, mb = (float)s0 / n, mg = (float)s1 / n;
-  for (int r = 0; r < n; ++r) {
-    float g = dy[(size_t)r * c + ch];
-    if (relu && !(y[(size_t)r * c + ch] > 0.f)) g = 0.f;
-    if (dres != nullptr) dres[(size_t)r * c + ch] = g;
-    dx[(size_t)r * c + ch] = k * (g - mb - (x[(size_t)r * c + ch] - mu) * is * mg);
-  }
+  dbeta[ch] = (float)t0;
+  dgamma[ch] = (float)t1;
 }
 
 static inline int ew_grid(size_t nvec) {
@@ -241,70 +275,79 @@ static inline int ew_grid(size_t nvec) {
 
 using namespace cstp;
 
-extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s) {
+extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups) {
   (void)s;
-  if (n <= 0 || c <= 0) return 0;
-  return align_up((size_t)c * bn_nsplit(n, c) * 2 * sizeof(double), 256);
+  if (n <= 0 || c <= 0 || groups <= 0 || (n % groups) != 0) return 0;
+  const int npg = n / groups;
+  // [c][groups][nsplit][2] fp64 partials, then [groups][c][2] fp32 per-group backward sums
+  return align_up((size_t)c * groups * bn_nsplit(npg, c) * 2 * sizeof(double), 256) +
+         align_up((size_t)groups * c * 2 * sizeof(float), 256);
 }
 
 extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var, float* save_mean,
-                                     float* save_invstd, int32_t n, int32_t c, int32_t s, float eps, float momentum,
-                                     int32_t relu, void* ws, size_t ws_bytes) {
+                                     float* save_invstd, int32_t n, int32_t c, int32_t s, int32_t groups, float eps,
+                                     float momentum, int32_t relu, void* ws, size_t ws_bytes) {
   CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "null argument");
-  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
   CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
-  CSTP_REQUIRE((size_t)n * s > 1, "train-mode BatchNorm needs more than 1 value per channel");
+  const int npg = n / groups;
+  CSTP_REQUIRE((size_t)npg * s > 1, "train-mode BatchNorm needs more than 1 value per channel");
   hipStream_t st = as_stream(stream);
   if (s == 1) {
     hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, residual, y, gamma, beta, running_mean,
-                       running_var, save_mean, save_invstd, n, c, eps, momentum, relu);
+                       running_var, save_mean, save_invstd, npg, groups, c, eps, momentum, relu);
     CSTP_LAUNCH_CHECK();
     return 0;
   }
-  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s), "workspace too small");
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
   double* part = reinterpret_cast<double*>(ws);
-  const int ns = bn_nsplit(n, c);
+  const int ns = bn_nsplit(npg, c);
   const bool v4 = (s % 4) == 0;
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), dim3(c, ns), dim3(256), 0, st, x, x, x, nullptr, nullptr, part, n, c, s, ns, 0);
-  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(c, ns), dim3(256), 0, st, x, x, x, nullptr, nullptr, part, n, c, s, ns, 0);
+  const dim3 rgrid(c, groups * ns);
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0);
+  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0);
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
-                     running_var, c, ns, (double)n * s, eps, momentum);
+                     running_var, c, groups, ns, (double)npg * s, eps, momentum);
   CSTP_LAUNCH_CHECK();
   const size_t total = (size_t)n * c * s;
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, relu);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, relu);
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
                                 const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
-                                float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t relu, void* ws,
-                                size_t ws_bytes) {
+                                float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups, int32_t relu,
+                                void* ws, size_t ws_bytes) {
   CSTP_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
-  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
+  const int npg = n / groups;
   hipStream_t st = as_stream(stream);
   if (s == 1) {
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, y, dy, gamma, save_mean, save_invstd, dx,
-                       dresidual, dgamma, dbeta, n, c, relu);
+                       dresidual, dgamma, dbeta, npg, groups, c, relu);
     CSTP_LAUNCH_CHECK();
     return 0;
   }
-  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s), "workspace too small");
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
   double* part = reinterpret_cast<double*>(ws);
-  const int ns = bn_nsplit(n, c);
+  const int ns = bn_nsplit(npg, c);
+  float* gsum = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                         align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
   const bool v4 = (s % 4) == 0;
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(c, ns), dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, n, c, s, ns, relu);
-  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(c, ns), dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, n, c, s, ns, relu);
+  const dim3 rgrid(c, groups * ns);
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu);
+  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, c, ns);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
   CSTP_LAUNCH_CHECK();
   const size_t total = (size_t)n * c * s;
-  const float inv_count = (float)(1.0 / ((double)n * s));
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, dgamma, dbeta, dx, dresidual, total, c, s, inv_count, relu);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, dgamma, dbeta, dx, dresidual, total, c, s, inv_count, relu);
+  const float inv_count = (float)(1.0 / ((double)npg * s));
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

@@ -68,11 +68,18 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // ------------------------------------------------------------------------------------------
 // K1: forward / data-gradient implicit GEMM
 // ------------------------------------------------------------------------------------------
-template <int MT, bool DGRAD, bool STRADDLE>
+// WM = waves along M (1, 2 or 4), 4/WM waves along N: block tile (32*MT*WM) x (32*4/WM).  The wide
+// 128-column tile (WM = 1) serves the big early layers; the 64- and 32-column tiles keep >= 256
+// blocks in flight on the deep layers, whose position count is small (2B*2*7*7) but K is long.
+template <int MT, int WM, bool DGRAD, bool STRADDLE>
 __global__ void __launch_bounds__(256)
 igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ src, const float* __restrict__ bias,
          float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
-  constexpr int BM = 32 * MT, BN = 128, BK = 16;
+  constexpr int WN = 4 / WM;
+  constexpr int BM = 32 * MT * WM, BN = 32 * WN, BK = 16;
+  constexpr int BR = BK * BN / 256;      // B-tile rows gathered per thread (8 / 4 / 2)
+  constexpr int BRS = 256 / BN;          // row stride between them (2 / 4 / 8)
+  static_assert(BM <= 160, "A staging holds at most 3 float4 per thread");
   __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
@@ -104,8 +111,8 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
   const int khw = g.kh * g.kw, ntaps = g.kt * khw;
 
-  // ---- loader coordinates: this thread gathers column `col` of the B tile, rows krow0 + 2r
-  const int col = t & 127, krow0 = t >> 7;
+  // ---- loader coordinates: this thread gathers column `col` of the B tile, rows krow0 + BRS*r
+  const int col = t % BN, krow0 = t / BN;
   const bool nvalid = (n0 + col) < npos;
   int nb, npd, nph, npw;
   {
@@ -126,7 +133,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   constexpr int A_ITERS = (A_F4 + 255) / 256;
   float4 ra0, ra1, ra2;   // named registers (an indexed array here ends up in scratch)
   ra0 = ra1 = ra2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float rb[8];
+  float rb[BR];
   static_assert(A_ITERS <= 3, "A tile staging assumes at most 3 float4 per thread");
 
   // iteration state
@@ -179,8 +186,8 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
       if (A_ITERS > 2) ra2 = a_at(2);
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int kr = krow0 + 2 * r;
+    for (int r = 0; r < BR; ++r) {
+      const int kr = krow0 + BRS * r;
       // Loads are UNCONDITIONAL (address clamped to element 0 when masked) and the zero is selected
       // afterwards: a branch around each load makes hipcc wait vmcnt(0) per element (serialised).
       bool ok;
@@ -208,7 +215,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     if (A_ITERS > 1 && t + 256 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 256) * 4]) = ra1;
     if (A_ITERS > 2 && t + 512 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 512) * 4]) = ra2;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) Bs[buf][(krow0 + 2 * r) * BN + col] = rb[r];
+    for (int r = 0; r < BR; ++r) Bs[buf][(krow0 + BRS * r) * BN + col] = rb[r];
   };
 
   bool have = first_tile();
@@ -216,16 +223,17 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   __syncthreads();
   int buf = 0;
   const int lrow = lane >> 5, lcol = lane & 31;
+  const int wm = wave % WM, wn = wave / WM;
   while (have) {
     const bool have_next = advance();
     if (have_next) load_tile();
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int kr = kk + lrow;
-      const float b = Bs[buf][kr * BN + wave * 32 + lcol];
+      const float b = Bs[buf][kr * BN + wn * 32 + lcol];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float a = As[buf][kr * BM + mt * 32 + lcol];
+        const float a = As[buf][kr * BM + (wm * MT + mt) * 32 + lcol];
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
       }
     }
@@ -236,7 +244,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   }
 
   // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int n = n0 + wave * 32 + lcol;
+  const int n = n0 + wn * 32 + lcol;
   if (n < npos) {
     size_t obase, cstride;
     if (DGRAD) {
@@ -257,7 +265,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
         if (m < g.M) {
           float v = acc[mt][r];
           if (bias != nullptr) v += bias[m];
@@ -275,9 +283,15 @@ template <int MT, bool STRADDLE>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
          int Jp, int ktiles_total, int ktiles_per_split) {
-  constexpr int BM = 32 * MT, BJ = 128, BKN = 64, LD = BKN + 1;
-  __shared__ float As[BM * LD];
-  __shared__ float Bs[BJ * LD];
+  // Block tile (32*MT) x 128 outputs; the reduction runs over positions in tiles of 32, staged
+  // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
+  // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
+  // while the current one is multiplied (LDS double buffered, one barrier per tile).
+  constexpr int BM = 32 * MT, BJ = 128, BKN = 32, LD = BKN + 1;
+  constexpr int AR = BM / 8;    // dy rows per thread
+  constexpr int BR = 16;        // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
+  __shared__ float As[2][BM * LD];
+  __shared__ float Bs[2][BJ * LD];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = blockIdx.x * BM, j0 = blockIdx.y * BJ;
@@ -286,6 +300,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   const int kt_begin = blockIdx.z * ktiles_per_split;
   int kt_end = kt_begin + ktiles_per_split;
   if (kt_end > ktiles_total) kt_end = ktiles_total;
+  if (kt_begin >= kt_end) return;
 
   const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
   const int khw = g.kh * g.kw;
@@ -307,9 +322,13 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int lrow = lane >> 5, lcol = lane & 31;
+  const int pos = t & 31, arow = t >> 5;     // A loader: position within the tile, first dy row
+  float va[AR], vb[BR];
+  bool a_valid = false;                       // this thread's position exists (tile-level)
+  unsigned b_mask = 0;                        // per-row validity of the gathered x elements
 
-  for (int kti = kt_begin; kti < kt_end; ++kti) {
-    const int n = kti * BKN + lane;
+  auto load_tile = [&](int kti) __attribute__((always_inline)) {
+    const int n = kti * BKN + pos;
     const bool nvalid = n < npos;
     int b = 0, sp = 0, od = 0, oh = 0, ow = 0;
     if (nvalid) {
@@ -318,21 +337,14 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       ow = q % g.Wp; q /= g.Wp;
       oh = q % g.Hp; od = q / g.Hp;
     }
-    // A tile: dy rows m = wave + 4r
-    {
-      const size_t ab = (size_t)b * g.M * S + sp;
-      float va[BM / 4];
+    a_valid = nvalid;
+    const size_t ab = (size_t)b * g.M * S + sp;
 #pragma unroll
-      for (int r = 0; r < BM / 4; ++r) {      // unconditional clamped loads (see K1), batched by the compiler
-        const int m = wave + 4 * r;
-        const bool ok = nvalid && (m0 + m) < g.M;
-        const float v = dy[ok ? ab + (size_t)(m0 + m) * S : 0];
-        va[r] = ok ? v : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < BM / 4; ++r) As[(wave + 4 * r) * LD + lane] = va[r];
+    for (int r = 0; r < AR; ++r) {            // unconditional clamped loads, zero selected at store time
+      const int m = m0 + arow + 8 * r;
+      va[r] = dy[(nvalid && m < g.M) ? ab + (size_t)m * S : 0];
     }
-    // B tile: this wave gathers exactly the 32 columns it consumes
+    b_mask = 0;
     if (wave_active) {
       const size_t xb = (size_t)b * g.Cs * DHWs;
       if (!STRADDLE) {
@@ -340,44 +352,63 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
         const bool v0 = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
                         (unsigned)iw < (unsigned)g.Ws;
         const int toff = id * HWs + ih * g.Ws + iw;
-        float vb[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          const int c = cw0 + r;
+        for (int r = 0; r < BR; ++r) {
+          const int c = cw0 + lrow + 2 * r;
           const bool ok = v0 && c < g.Cs;
-          const float v = x[ok ? xb + (size_t)c * DHWs + toff : 0];
-          vb[r] = ok ? v : 0.f;
+          vb[r] = x[ok ? xb + (size_t)c * DHWs + toff : 0];
+          b_mask |= (ok ? 1u : 0u) << r;
         }
-#pragma unroll
-        for (int r = 0; r < 32; ++r) Bs[(wave * 32 + r) * LD + lane] = vb[r];
       } else {
-#pragma unroll 4
-        for (int r = 0; r < 32; ++r) {
-          const int j = jw0 + r;
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+          const int j = jw0 + lrow + 2 * r;
           const int jc = j < Jtot ? j : 0;
           const int tp = jc / g.Cp, c = jc - tp * g.Cp;
           const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
           const int id = od * g.st - g.pt + dt, ih = oh * g.sh - g.ph + dh, iw = ow * g.sw - g.pw + dw;
-          const bool ok = nvalid && j < Jtot && c < g.Cs && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs &&
-                          (unsigned)iw < (unsigned)g.Ws;
-          const float v = x[ok ? xb + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw : 0];
-          Bs[(wave * 32 + r) * LD + lane] = ok ? v : 0.f;
+          const bool ok = nvalid && j < Jtot && c < g.Cs && (unsigned)id < (unsigned)g.Ds &&
+                          (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+          vb[r] = x[ok ? xb + (size_t)c * DHWs + id * HWs + ih * g.Ws + iw : 0];
+          b_mask |= (ok ? 1u : 0u) << r;
         }
       }
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      const int ml = arow + 8 * r;
+      As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
+    }
     if (wave_active) {
-#pragma unroll 8
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+        Bs[buf][(wave * 32 + lrow + 2 * r) * LD + lcol] = ((b_mask >> r) & 1u) ? vb[r] : 0.f;
+    }
+  };
+
+  load_tile(kt_begin);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kti = kt_begin; kti < kt_end; ++kti) {
+    const bool have_next = (kti + 1) < kt_end;
+    if (have_next) load_tile(kti + 1);
+    if (wave_active) {
+#pragma unroll
       for (int kk = 0; kk < BKN; kk += 2) {
-        const float bv = Bs[(wave * 32 + lcol) * LD + kk + lrow];
+        const float bv = Bs[buf][(wave * 32 + lcol) * LD + kk + lrow];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const float av = As[(mt * 32 + lcol) * LD + kk + lrow];
+          const float av = As[buf][(mt * 32 + lcol) * LD + kk + lrow];
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
         }
       }
     }
+    if (have_next) store_tile(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 
   const int j = jw0 + lcol;
@@ -396,7 +427,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int pick_mt(int M) {
+static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
   int best = 1;
   double bestc = 1e30;
   for (int mt = 1; mt <= 5; ++mt) {
@@ -407,12 +438,33 @@ static int pick_mt(int M) {
   return best;
 }
 
+struct Tile { int mt, wm; };
+
+// K1 tile choice: minimise (padded work) / (tile efficiency x grid fill).  Efficiency model: operand
+// traffic per FLOP grows with (1/BM + 1/BN); a grid below one block per CU leaves CUs idle.
+static Tile pick_tile(int M, long npos, int nclass) {
+  static const Tile cand[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {1, 2}, {2, 2}, {1, 4}};
+  Tile best = cand[0];
+  double bestc = 1e300;
+  for (const Tile& t : cand) {
+    const int bm = 32 * t.mt * t.wm, bn = 32 * (4 / t.wm);
+    const double ntm = cdiv(M, bm), ntx = (double)((npos + bn - 1) / bn);
+    const double padded = ntm * bm * ntx * bn;
+    const double eff = 1.0 / (1.0 + 8.0 * (1.0 / bm + 1.0 / bn));
+    const double blocks = ntm * ntx * nclass;
+    const double fill = blocks >= 256.0 ? 1.0 : blocks / 256.0;
+    const double c = padded / (eff * fill);
+    if (c < bestc * (1.0 - 1e-9)) { bestc = c; best = t; }
+  }
+  return best;
+}
+
 struct ConvPlan {
   int Do, Ho, Wo, ntaps;
   // forward
-  int f_mt, f_Cp, f_Mp, f_Kp; bool f_straddle;
+  Tile f_t; int f_Cp, f_Mp, f_Kp; bool f_straddle;
   // dgrad
-  int d_mt, d_Cp, d_Mp, d_Kp;
+  Tile d_t; int d_Cp, d_Mp, d_Kp;
   // wgrad
   int w_mt, w_Cp, w_Jtot, w_Jp; bool w_straddle;
 };
@@ -427,16 +479,16 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   if (p.Do <= 0 || p.Ho <= 0 || p.Wo <= 0) return false;
   p.ntaps = d.kt * d.kh * d.kw;
   // forward: M = k, gather channels = c
-  p.f_mt = pick_mt(d.k);
+  p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
   p.f_straddle = (d.c < 8);
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
-  p.f_Mp = cdiv(d.k, 32 * p.f_mt) * 32 * p.f_mt;
+  p.f_Mp = cdiv(d.k, 32 * p.f_t.mt * p.f_t.wm) * 32 * p.f_t.mt * p.f_t.wm;
   // dgrad: M = c, gather channels = k
-  p.d_mt = pick_mt(d.c);
+  p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
-  p.d_Mp = cdiv(d.c, 32 * p.d_mt) * 32 * p.d_mt;
+  p.d_Mp = cdiv(d.c, 32 * p.d_t.mt * p.d_t.wm) * 32 * p.d_t.mt * p.d_t.wm;
   // wgrad: M = k, J = (tap, c)
   p.w_mt = pick_mt(d.k);
   p.w_straddle = (d.c < 8);
@@ -454,15 +506,24 @@ static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
 }
 
 template <bool DGRAD, bool STRADDLE>
-static void launch_k1(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
+static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
                       const float* bias, float* out, int ntx, int ntm) {
-  switch (mt) {
-    case 1: hipLaunchKernelGGL((igemm_k1<1, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
-    case 2: hipLaunchKernelGGL((igemm_k1<2, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
-    case 3: hipLaunchKernelGGL((igemm_k1<3, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
-    case 4: hipLaunchKernelGGL((igemm_k1<4, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
-    default: hipLaunchKernelGGL((igemm_k1<5, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm); break;
+#define CSTP_K1(MT_, WM_) \
+  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm)
+  if (tl.wm == 1) {
+    switch (tl.mt) {
+      case 1: CSTP_K1(1, 1); break;
+      case 2: CSTP_K1(2, 1); break;
+      case 3: CSTP_K1(3, 1); break;
+      case 4: CSTP_K1(4, 1); break;
+      default: CSTP_K1(5, 1); break;
+    }
+  } else if (tl.wm == 2) {
+    if (tl.mt == 1) CSTP_K1(1, 2); else CSTP_K1(2, 2);
+  } else {
+    CSTP_K1(1, 4);
   }
+#undef CSTP_K1
 }
 
 template <bool STRADDLE>
@@ -512,10 +573,11 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.f_Cp; g.M = d.k; g.Mp = p.f_Mp; g.Ktot = p.ntaps * p.f_Cp;
   const int npos = d.n * p.Do * p.Ho * p.Wo;
-  const int ntx = cdiv(npos, 128), ntm = cdiv(d.k, 32 * p.f_mt);
+  const int f_bm = 32 * p.f_t.mt * p.f_t.wm, f_bn = 32 * (4 / p.f_t.wm);
+  const int ntx = cdiv(npos, f_bn), ntm = cdiv(d.k, f_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
-  if (p.f_straddle) launch_k1<false, true>(p.f_mt, grid, s, g, wp, x, bias, y, ntx, ntm);
-  else launch_k1<false, false>(p.f_mt, grid, s, g, wp, x, bias, y, ntx, ntm);
+  if (p.f_straddle) launch_k1<false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm);
+  else launch_k1<false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -541,9 +603,10 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   g.Cp = p.d_Cp; g.M = d.c; g.Mp = p.d_Mp; g.Ktot = p.ntaps * p.d_Cp;
   const int nclass = d.st * d.sh * d.sw;
   const int npos_max = d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw);
-  const int ntx = cdiv(npos_max, 128), ntm = cdiv(d.c, 32 * p.d_mt);
+  const int d_bm = 32 * p.d_t.mt * p.d_t.wm, d_bn = 32 * (4 / p.d_t.wm);
+  const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
-  launch_k1<true, false>(p.d_mt, grid, s, g, wp, dy, nullptr, dx, ntx, ntm);
+  launch_k1<true, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -567,10 +630,10 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
   const int npos = d.n * p.Do * p.Ho * p.Wo;
-  const int kt_total = cdiv(npos, 64);
+  const int kt_total = cdiv(npos, 32);
   const int ntm = cdiv(d.k, 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
   int splits = cdiv(1024, ntm * ntj);
-  if (splits > cdiv(kt_total, 4)) splits = cdiv(kt_total, 4);
+  if (splits > cdiv(kt_total, 8)) splits = cdiv(kt_total, 8);
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
   splits = cdiv(kt_total, kt_per);

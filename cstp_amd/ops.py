@@ -141,7 +141,7 @@ def linear(x, w, bias=None):
 # ----------------------------------------------------------------------------------------------
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
         lib = _lib.load()
         x = _req(x, "batch_norm input")
         gamma = _req(gamma, "batch_norm weight")
@@ -151,17 +151,20 @@ class _BNAct(torch.autograd.Function):
         res = None if residual is None else _req(residual, "residual")
         if res is not None and res.shape != x.shape:
             raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
+        if groups < 1 or n % groups != 0:
+            raise _lib.CstpError("batch of %d rows cannot be split into %d BN groups" % (n, groups))
         y = torch.empty_like(x)
-        mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-        nbytes = lib.cstp_bn_workspace_bytes(n, c, s)
+        mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        nbytes = lib.cstp_bn_workspace_bytes(n, c, s, groups)
         ws = _workspace(x.device, nbytes)
         check(lib.cstp_bn_forward_train(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), n, c, s,
-                                        eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
+                                        groups, eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
               "cstp_bn_forward_train")
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu = relu
+        ctx.groups = groups
         ctx.has_res = res is not None
         return y
 
@@ -176,18 +179,20 @@ class _BNAct(torch.autograd.Function):
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(gamma)
-        nbytes = lib.cstp_bn_workspace_bytes(n, c, s)
+        nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)
         ws = _workspace(x.device, nbytes)
         check(lib.cstp_bn_backward(_stream(), x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                    invstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n, c, s,
-                                   1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+                                   ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual=None, relu=False, eps=BN_EPS,
-                   momentum=BN_MOMENTUM):
-    """y = act(batch_norm_train(x) + residual); running stats updated in place."""
-    return _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum))
+                   momentum=BN_MOMENTUM, groups=1):
+    """y = act(batch_norm_train(x) + residual); running stats updated in place.  ``groups`` > 1: the batch is
+    that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
+    return _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
+                        int(groups))
 
 
 # ----------------------------------------------------------------------------------------------

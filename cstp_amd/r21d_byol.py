@@ -68,13 +68,13 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, groups=1):
         if not self.training:
             raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
         y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps,
-                               self.momentum)
+                               self.momentum, groups)
         if not getattr(self, "_nbt_in_arena", False):
-            self.num_batches_tracked += 1   # else: one add per net per forward, see R21DBYOL.forward
+            self.num_batches_tracked += groups   # else: one add per net per forward, see R21DBYOL.forward
         return y
 
 
@@ -113,12 +113,12 @@ class _MLP(nn.Sequential):
     def __init__(self, dim, hidden, out):
         super().__init__(Linear(dim, hidden), BatchNorm1d(hidden), ReLU(), Linear(hidden, out))
 
-    def forward(self, x):
-        if x.shape[0] < 2:
+    def forward(self, x, groups=1):
+        if x.shape[0] // groups < 2:
             # same failure the reference hits in nn.BatchNorm1d (train mode)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
         h = self[0](x)
-        h = self[1](h, relu=True)
+        h = self[1](h, relu=True, groups=groups)
         return self[3](h)
 
 
@@ -141,8 +141,8 @@ class SpatioTemporalConv(nn.Module):
         self.temporal_conv = Conv3d(intermed_channels, out_channels, (kernel_size[0], 1, 1), stride=(stride[0], 1, 1),
                                     padding=(padding[0], 0, 0), bias=bias)
 
-    def forward(self, x):
-        x = self.bn(self.spatial_conv(x), relu=True)
+    def forward(self, x, groups=1):
+        x = self.bn(self.spatial_conv(x), relu=True, groups=groups)
         return self.temporal_conv(x)
 
 
@@ -163,13 +163,13 @@ class SpatioTemporalResBlock(nn.Module):
         self.bn2 = BatchNorm3d(out_channels)
         self.outrelu = ReLU()
 
-    def forward(self, x):
-        res = self.bn1(self.conv1(x), relu=True)
-        res = self.conv2(res)
+    def forward(self, x, groups=1):
+        res = self.bn1(self.conv1(x, groups), relu=True, groups=groups)
+        res = self.conv2(res, groups)
         if self.downsample:
-            x = self.downsamplebn(self.downsampleconv(x))
+            x = self.downsamplebn(self.downsampleconv(x, groups), groups=groups)
         # relu(x + bn2(res)) as one kernel (r21d_byol.py:143,148)
-        return self.bn2(res, residual=x, relu=True)
+        return self.bn2(res, residual=x, relu=True, groups=groups)
 
 
 class SpatioTemporalResLayer(nn.Module):
@@ -181,10 +181,10 @@ class SpatioTemporalResLayer(nn.Module):
         for _ in range(layer_size - 1):
             self.blocks += [block_type(out_channels, out_channels, kernel_size)]
 
-    def forward(self, x):
-        x = self.block1(x)
+    def forward(self, x, groups=1):
+        x = self.block1(x, groups)
         for block in self.blocks:
-            x = block(x)
+            x = block(x, groups)
         return x
 
 
@@ -193,8 +193,8 @@ class Projector(nn.Module):
         super().__init__()
         self.net = _MLP(dim, projection_hidden_size, projection_size)
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, groups=1):
+        return self.net(x, groups)
 
 
 class Predictor(nn.Module):
@@ -202,8 +202,8 @@ class Predictor(nn.Module):
         super().__init__()
         self.net = _MLP(dim, prediction_hidden_size, prediction_size)
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, groups=1):
+        return self.net(x, groups)
 
 
 class R2Plus1DNet(nn.Module):
@@ -220,15 +220,17 @@ class R2Plus1DNet(nn.Module):
         if self.proj_flag:
             self.project = Projector(dim=512, projection_size=512, projection_hidden_size=4096)
 
-    def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.conv2(x)
-        x = self.conv3(x)
-        x = self.conv4(x)
-        x = self.conv5(x)
+    def forward(self, x, groups=1):
+        """``groups`` > 1: x holds that many independent forward calls back to back along the batch axis
+        (BN statistics stay per call); convolutions are per-sample, so the result equals separate calls."""
+        x = self.bn1(self.conv1(x, groups), relu=True, groups=groups)
+        x = self.conv2(x, groups)
+        x = self.conv3(x, groups)
+        x = self.conv4(x, groups)
+        x = self.conv5(x, groups)
         x = ops.global_avg_pool(x)  # AdaptiveAvgPool3d(1) + view(-1, 512)
         if self.proj_flag:
-            return x, self.project(x)
+            return x, self.project(x, groups)
         return x
 
 
@@ -356,30 +358,38 @@ class R21DBYOL(nn.Module):
 
     def forward(self, x1, x2=None, o_type=None):
         if o_type == "loss_com":
-            online_feat_1, online_feat_1_proj = self.online_net(x1)
-            online_feat_2, online_feat_2_proj = self.online_net(x2)
-            online_feat_1_pred = self.predictor(online_feat_1_proj)
-            online_feat_2_pred = self.predictor(online_feat_2_proj)
+            if x2 is None or x2.shape != x1.shape:
+                raise ValueError("o_type='loss_com' needs two clips of identical shape")
+            b = x1.shape[0]
+            # Both views go through ONE launch sequence per network as a batch of 2B with two BN groups:
+            # convolutions are per-sample and BN statistics stay per view, so this is the reference's
+            # online_net(x1); online_net(x2) (r21d_byol.py:359-360) with half the launches, one weight
+            # pack per layer and twice the grid on the small deep layers.
+            x = torch.cat((x1, x2), dim=0)
+            online_feat, online_proj = self.online_net(x, groups=2)
+            online_pred = self.predictor(online_proj, groups=2)
             with torch.no_grad():
-                self._update_target_net()
-                _, target_feat_1_proj = self.target_net(x1)
-                _, target_feat_2_proj = self.target_net(x2)
-            loss = self._cal_loss(online_feat_1_pred, online_feat_2_pred, target_feat_1_proj.detach(),
-                                  target_feat_2_proj.detach())
+                self._update_target_net()                      # EMA BEFORE the target forward (:364)
+                _, target_proj = self.target_net(x, groups=2)  # train-mode BN, own running stats (:365-366)
+                target_swapped = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
+            # loss_fn(pred_1, tproj_2) + loss_fn(pred_2, tproj_1)  (:351-355)
+            rows = self._loss_fn(online_pred, target_swapped)
+            loss = rows[:b] + rows[b:]
+            online_feat_1, online_feat_2 = online_feat[:b], online_feat[b:]
             feat_cat = torch.cat((online_feat_1, online_feat_2), dim=1)
             pred_spa = self.overlap_spa(feat_cat)
             pred_tem = self.overlap_tem(feat_cat)
-            pred_pb_1 = self.pb_cls(online_feat_1)
-            pred_pb_2 = self.pb_cls(online_feat_2)
-            pred_rot_1 = self.rotate_cls(online_feat_1)
-            pred_rot_2 = self.rotate_cls(online_feat_2)
+            pred_pb = self.pb_cls(online_feat, groups=2)
+            pred_rot = self.rotate_cls(online_feat, groups=2)
+            pred_pb_1, pred_pb_2 = pred_pb[:b], pred_pb[b:]
+            pred_rot_1, pred_rot_2 = pred_rot[:b], pred_rot[b:]
             if self._arenas is not None:   # BN num_batches_tracked: three adds instead of 108
                 nbt = self._arenas["nbt"]
                 nbt["online"] += 2
                 nbt["target"] += 2
                 nbt["heads"] += nbt["heads_inc"]
-            # kept for the NT-Xent head and for parity tests (detached views, no extra work)
-            self.last_projections = (online_feat_1_proj, online_feat_2_proj)
+            # kept for the NT-Xent head and for parity tests (no extra work)
+            self.last_projections = (online_proj[:b], online_proj[b:])
             return loss.mean(), (pred_spa, pred_tem, pred_pb_1, pred_pb_2, pred_rot_1, pred_rot_2)
         elif o_type == "r_byol":
             raise NotImplementedError("o_type='r_byol' is shape-broken in the reference (predictor fed a tuple, "

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 1
+#define CSTP_ABI_VERSION 2
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -58,19 +58,22 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
 /* ---- BatchNorm3d / BatchNorm1d in TRAIN mode, fused with the residual add and ReLU that follow
  *      it (r21d_byol.py:83-84,133-134,138-139,148,199-200,216; Projector/Predictor/heads BN1d).
  *      x,y,residual: [n][c][s] (s = D*H*W).  y = act(bn(x) + residual), act = relu if relu != 0.
- *      save_mean/save_invstd: [c] outputs for backward.  running_mean/var updated in place with
- *      `momentum` (unbiased variance), as F.batch_norm(training=True) does. */
-size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s);
+ *      `groups`: the batch holds that many independent BN calls back to back (n = groups * n_per_group,
+ *      e.g. the two views of a clip pair, r21d_byol.py:359-360): statistics are per (group, channel),
+ *      running stats are updated group after group as successive F.batch_norm(training=True) calls would.
+ *      save_mean/save_invstd: [groups][c] outputs for backward.  running_mean/var updated in place with
+ *      `momentum` (unbiased variance). */
+size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups);
 int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, float* save_mean,
-                          float* save_invstd, int32_t n, int32_t c, int32_t s, float eps, float momentum,
-                          int32_t relu, void* ws, size_t ws_bytes);
+                          float* save_invstd, int32_t n, int32_t c, int32_t s, int32_t groups, float eps,
+                          float momentum, int32_t relu, void* ws, size_t ws_bytes);
 /* Backward of the fused op.  y is the forward OUTPUT (its sign is the ReLU mask).  dresidual may be
- * NULL.  dgamma/dbeta: [c]. */
+ * NULL.  dgamma/dbeta: [c], summed over the groups (they share the affine parameters). */
 int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
                      const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
-                     float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t relu, void* ws,
-                     size_t ws_bytes);
+                     float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups, int32_t relu,
+                     void* ws, size_t ws_bytes);
 
 /* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
 int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
     assert lib.cstp_conv3d_workspace_bytes(ctypes.byref(ok)) >= 9 * 64 * 160 * 4
     rc = lib.cstp_conv3d_forward(None, ctypes.byref(ok), None, None, None, None, None, 0)
     assert rc != 0 and b"null argument" in lib.cstp_last_error()
-    assert lib.cstp_bn_workspace_bytes(16, 144, 50176) > 0
+    assert lib.cstp_bn_workspace_bytes(16, 144, 50176, 1) > 0 and lib.cstp_bn_workspace_bytes(15, 144, 50176, 2) == 0
     assert lib.cstp_ntxent_workspace_bytes(32, 512) >= (2 * 32 + 2 * 32 * 32) * 4
 
 

@@ -121,6 +121,31 @@ def test_bn_act_fwd_bwd(shape, use_res, relu):
         assert rel_err(rg.grad, res.grad) < TOL
 
 
+@pytest.mark.parametrize("shape,relu", [((6, 24, 2, 6, 6), True), ((8, 40), True), ((4, 9, 1, 7, 7), False)])
+def test_bn_groups_equal_successive_calls(shape, relu):
+    """groups=2 over a 2B batch == two successive F.batch_norm calls (per-view stats, sequential running stats)."""
+    from cstp_amd import ops
+    c, half = shape[1], shape[0] // 2
+    x = (_rand(shape, 31) * 1.5 + 0.3).requires_grad_(True)
+    gamma = _rand((c,), 32).requires_grad_(True)
+    beta = (_rand((c,), 33) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    ys = [F.batch_norm(x[i * half:(i + 1) * half], rm, rv, gamma, beta, True, 0.1, 1e-5) for i in range(2)]
+    y = torch.cat(ys, 0)
+    if relu:
+        y = F.relu(y)
+    dy = _rand(shape, 34)
+    y.backward(dy)
+    xg = x.detach().float().cuda().requires_grad_(True)
+    gg = gamma.detach().float().cuda().requires_grad_(True)
+    bg = beta.detach().float().cuda().requires_grad_(True)
+    rmg, rvg = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    yg = ops.batch_norm_act(xg, gg, bg, rmg, rvg, None, relu, groups=2)
+    yg.backward(dy.float().cuda())
+    assert rel_err(yg, y) < TOL and rel_err(rmg, rm) < TOL and rel_err(rvg, rv) < TOL
+    assert rel_err(xg.grad, x.grad) < TOL and rel_err(gg.grad, gamma.grad) < TOL and rel_err(bg.grad, beta.grad) < TOL
+
+
 def test_bn_rejects_single_value():
     from cstp_amd import ops, _lib
     x = torch.ones(1, 8, device="cuda")
