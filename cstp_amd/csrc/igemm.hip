@@ -15,6 +15,10 @@
 // (coalesced along n, the NCDHW-contiguous axis) and double buffered in LDS.
 #include "common.h"
 
+#ifndef CSTP_PIN_PREFETCH
+#define CSTP_PIN_PREFETCH 0
+#endif
+
 namespace cstp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -227,14 +231,32 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   while (have) {
     const bool have_next = advance();
     if (have_next) load_tile();
+    {
+      // operand fragments of k-pair kk+2 are read from LDS while the MFMAs of k-pair kk run
+      const float* Ab = &As[buf][lrow * BM + wm * MT * 32 + lcol];
+      const float* Bb = &Bs[buf][lrow * BN + wn * 32 + lcol];
+      float a_cur[MT], a_nxt[MT], b_cur, b_nxt = 0.f;
+      b_cur = Bb[0];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int kr = kk + lrow;
-      const float b = Bs[buf][kr * BN + wn * 32 + lcol];
+      for (int mt = 0; mt < MT; ++mt) { a_cur[mt] = Ab[mt * 32]; a_nxt[mt] = 0.f; }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float a = As[buf][kr * BM + (wm * MT + mt) * 32 + lcol];
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+      for (int kk = 0; kk < BK; kk += 2) {
+        if (kk + 2 < BK) {
+          b_nxt = Bb[(kk + 2) * BN];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = Ab[(kk + 2) * BM + mt * 32];
+        }
+#if CSTP_PIN_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
+#endif
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
+#if CSTP_PIN_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        b_cur = b_nxt;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
       }
     }
     if (have_next) store_tile(buf ^ 1);
@@ -396,14 +418,30 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     const bool have_next = (kti + 1) < kt_end;
     if (have_next) load_tile(kti + 1);
     if (wave_active) {
+      const float* Ab = &As[buf][lcol * LD + lrow];
+      const float* Bb = &Bs[buf][(wave * 32 + lcol) * LD + lrow];
+      float a_cur[MT], a_nxt[MT], b_cur, b_nxt = 0.f;
+      b_cur = Bb[0];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { a_cur[mt] = Ab[mt * 32 * LD]; a_nxt[mt] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < BKN; kk += 2) {
-        const float bv = Bs[buf][(wave * 32 + lcol) * LD + kk + lrow];
+        if (kk + 2 < BKN) {
+          b_nxt = Bb[kk + 2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float av = As[buf][(mt * 32 + lcol) * LD + kk + lrow];
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = Ab[mt * 32 * LD + kk + 2];
         }
+#if CSTP_PIN_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
+#endif
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
+#if CSTP_PIN_PREFETCH
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        b_cur = b_nxt;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
       }
     }
     if (have_next) store_tile(buf ^ 1);
