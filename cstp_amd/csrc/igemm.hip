@@ -301,25 +301,32 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // K2: weight gradient.  dwp[m][j] += sum_{n in split} dy[m][n] * xcol[j][n],  j = tap*Cp + c
 // ------------------------------------------------------------------------------------------
-template <int MT, bool STRADDLE>
+template <int MT, bool STRADDLE, bool VEC4>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
-         int Jp, int ktiles_total, int ktiles_per_split) {
+         int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
   // Block tile (32*MT) x 128 outputs; the reduction runs over positions in tiles of 32, staged
   // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
   // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
   // while the current one is multiplied (LDS double buffered, one barrier per tile).
   constexpr int BM = 32 * MT, BJ = 128, BKN = 32, LD = BKN + 1;
-  constexpr int AR = BM / 8;    // dy rows per thread
+  constexpr int AR = VEC4 ? MT : BM / 8;   // dy loads per thread (float4 of 4 positions, or single floats)
   constexpr int BR = 16;        // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.x * BM, j0 = blockIdx.y * BJ;
+  // XCD-aware order (blocks b, b+8 share an L2): the ntj column tiles that read the same dY panel of
+  // one (row tile, split) sit on consecutive slots of ONE xcd.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int jt = slot % ntj;
+  const int panel = (slot / ntj) * 8 + xcd;          // panel = (row tile, split): one dY stream
+  if (panel >= ntm * nsplit) return;
+  const int mtile = panel % ntm, split = panel / ntm;
+  const int m0 = mtile * BM, j0 = jt * BJ;
   const int S = g.Dp * g.Hp * g.Wp;
   const int npos = g.Nb * S;
-  const int kt_begin = blockIdx.z * ktiles_per_split;
+  const int kt_begin = split * ktiles_per_split;
   int kt_end = kt_begin + ktiles_per_split;
   if (kt_end > ktiles_total) kt_end = ktiles_total;
   if (kt_begin >= kt_end) return;
@@ -344,8 +351,10 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int lrow = lane >> 5, lcol = lane & 31;
-  const int pos = t & 31, arow = t >> 5;     // A loader: position within the tile, first dy row
-  float va[AR], vb[BR];
+  const int pos = t & 31, arow = t >> 5;     // scalar A loader: position within the tile, first dy row
+  const int q4 = t & 7, arow4 = t >> 3;      // float4 A loader: which 4 positions, first dy row (stride 32)
+  float va[VEC4 ? 4 * MT : AR], vb[BR];
+  bool a_valid4 = false;
   bool a_valid = false;                       // this thread's position exists (tile-level)
   unsigned b_mask = 0;                        // per-row validity of the gathered x elements
 
@@ -360,11 +369,26 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       oh = q % g.Hp; od = q / g.Hp;
     }
     a_valid = nvalid;
-    const size_t ab = (size_t)b * g.M * S + sp;
+    if (VEC4) {
+      // 4 consecutive positions never straddle a clip (S % 4 == 0) and are 16-byte aligned
+      const int n4 = kti * BKN + 4 * q4;
+      const bool v4 = n4 < npos;
+      const int b4 = v4 ? n4 / S : 0, sp4 = v4 ? n4 - b4 * S : 0;
+      a_valid4 = v4;
+      const size_t ab4 = (size_t)b4 * g.M * S + sp4;
 #pragma unroll
-    for (int r = 0; r < AR; ++r) {            // unconditional clamped loads, zero selected at store time
-      const int m = m0 + arow + 8 * r;
-      va[r] = dy[(nvalid && m < g.M) ? ab + (size_t)m * S : 0];
+      for (int r = 0; r < MT; ++r) {
+        const int m = m0 + arow4 + 32 * r;
+        const float4 v = *reinterpret_cast<const float4*>(dy + ((v4 && m < g.M) ? ab4 + (size_t)m * S : 0));
+        va[4 * r + 0] = v.x; va[4 * r + 1] = v.y; va[4 * r + 2] = v.z; va[4 * r + 3] = v.w;
+      }
+    } else {
+      const size_t ab = (size_t)b * g.M * S + sp;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {            // unconditional clamped loads, zero selected at store time
+        const int m = m0 + arow + 8 * r;
+        va[r] = dy[(nvalid && m < g.M) ? ab + (size_t)m * S : 0];
+      }
     }
     b_mask = 0;
     if (wave_active) {
@@ -398,10 +422,20 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    if (VEC4) {
 #pragma unroll
-    for (int r = 0; r < AR; ++r) {
-      const int ml = arow + 8 * r;
-      As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
+      for (int r = 0; r < MT; ++r) {
+        const int ml = arow4 + 32 * r;
+        const bool ok = a_valid4 && (m0 + ml) < g.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[buf][ml * LD + 4 * q4 + i] = ok ? va[4 * r + i] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        const int ml = arow + 8 * r;
+        As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
+      }
     }
     if (wave_active) {
 #pragma unroll
@@ -564,16 +598,19 @@ static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const fl
 #undef CSTP_K1
 }
 
-template <bool STRADDLE>
+template <bool STRADDLE, bool VEC4>
 static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* dy, const float* x, float* dwp,
-                      int Jtot, int Jp, int kt_total, int kt_per) {
+                      int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit) {
+#define CSTP_K2(MT_) \
+  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per, ntm, ntj, nsplit)
   switch (mt) {
-    case 1: hipLaunchKernelGGL((igemm_k2<1, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
-    case 2: hipLaunchKernelGGL((igemm_k2<2, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
-    case 3: hipLaunchKernelGGL((igemm_k2<3, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
-    case 4: hipLaunchKernelGGL((igemm_k2<4, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
-    default: hipLaunchKernelGGL((igemm_k2<5, STRADDLE>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per); break;
+    case 1: CSTP_K2(1); break;
+    case 2: CSTP_K2(2); break;
+    case 3: CSTP_K2(3); break;
+    case 4: CSTP_K2(4); break;
+    default: CSTP_K2(5); break;
   }
+#undef CSTP_K2
 }
 
 static int pack_grid(size_t total) {
@@ -675,9 +712,15 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
   splits = cdiv(kt_total, kt_per);
-  dim3 grid((unsigned)ntm, (unsigned)ntj, (unsigned)splits);
-  if (p.w_straddle) launch_k2<true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per);
-  else launch_k2<false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per);
+  dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
+  const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+  if (p.w_straddle) {
+    if (v4) launch_k2<true, true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else launch_k2<true, false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+  } else {
+    if (v4) launch_k2<false, true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else launch_k2<false, false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+  }
   CSTP_LAUNCH_CHECK();
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp);
