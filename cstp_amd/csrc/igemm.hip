@@ -89,13 +89,17 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (L2); the n_tiles_m blocks that read the
-  // same input panel get consecutive slots of ONE xcd so the panel is fetched into one L2 once.
+  // XCD-aware tile order: blocks b and b+8 share an XCD (L2).  Each XCD works through ONE contiguous
+  // chunk of position tiles (neighbouring tiles share their 3x3 / temporal halo rows, so the halo is
+  // an L2 hit instead of a second HBM fetch), and the n_tiles_m row tiles that read the same input
+  // panel occupy consecutive slots of that XCD.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int mtile = slot % n_tiles_m;
-  const int ntile = (slot / n_tiles_m) * 8 + xcd;
-  if (ntile >= n_tiles_x) return;
+  const int chunk = (n_tiles_x + 7) >> 3;
+  const int nt_in = slot / n_tiles_m;
+  const int ntile = xcd * chunk + nt_in;
+  if (nt_in >= chunk || ntile >= n_tiles_x) return;
 
   int zt = 0, zh = 0, zw = 0;
   int Dp = g.Dp, Hp = g.Hp, Wp = g.Wp;
@@ -512,8 +516,10 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
 
 struct Tile { int mt, wm; };
 
-// K1 tile choice: minimise (padded work) / (tile efficiency x grid fill).  Efficiency model: operand
-// traffic per FLOP grows with (1/BM + 1/BN); a grid below one block per CU leaves CUs idle.
+// K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
+// matrix pipes, so time ~ max blocks per CU x work per block); per-block work ~ BM x BN (K is fixed);
+// tile efficiency falls with operand traffic per FLOP (1/BM + 1/BN); a grid of <= 1 block per CU
+// cannot overlap its own loads with another block's MFMAs.
 static Tile pick_tile(int M, long npos, int nclass) {
   static const Tile cand[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {1, 2}, {2, 2}, {1, 4}};
   Tile best = cand[0];
@@ -521,11 +527,11 @@ static Tile pick_tile(int M, long npos, int nclass) {
   for (const Tile& t : cand) {
     const int bm = 32 * t.mt * t.wm, bn = 32 * (4 / t.wm);
     const double ntm = cdiv(M, bm), ntx = (double)((npos + bn - 1) / bn);
-    const double padded = ntm * bm * ntx * bn;
-    const double eff = 1.0 / (1.0 + 8.0 * (1.0 / bm + 1.0 / bn));
     const double blocks = ntm * ntx * nclass;
-    const double fill = blocks >= 256.0 ? 1.0 : blocks / 256.0;
-    const double c = padded / (eff * fill);
+    double eff = 1.0 / (1.0 + 8.0 * (1.0 / bm + 1.0 / bn));
+    if (blocks <= 256.0) eff *= 0.8;
+    const double rounds = blocks >= 2048.0 ? blocks / 256.0 : (double)(((long)blocks + 255) / 256);
+    const double c = rounds * bm * bn / eff;
     if (c < bestc * (1.0 - 1e-9)) { bestc = c; best = t; }
   }
   return best;
