@@ -62,6 +62,18 @@ class ConvTimer:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs, gfx950 x2 read correction calibrated on a known byte count) -- a profiler
+    measurement cannot be taken inside this process, so the number travels with the profile."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_dominant_kernel.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sample_b=2):
     """The CPU oracle (stock PyTorch CPU ops; `port`) on a bounded sample of the same workload."""
     from oracle import r21d_byol_oracle as orc
@@ -162,7 +174,10 @@ def main():
                                    % (args.depth, args.batch, T, HW, HW),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH) else None,
+                         "algorithmic_bytes_per_launch": 4.0 * (2 * args.batch * T * (HW // 2) * (HW // 2)) * (64 + 144)
+                         + 4.0 * 144 * 64 * 9,
                          "kernel": "igemm_k1<5,fwd> spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
                          "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
                          "algorithmic_gflop_per_launch": flops / 1e9},

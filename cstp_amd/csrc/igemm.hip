@@ -18,6 +18,12 @@
 #ifndef CSTP_PIN_PREFETCH
 #define CSTP_PIN_PREFETCH 0
 #endif
+#ifndef CSTP_SETPRIO
+#define CSTP_SETPRIO 0
+#endif
+#ifndef CSTP_K2_BKN
+#define CSTP_K2_BKN 32      // positions per weight-gradient reduction tile (32 or 64)
+#endif
 
 namespace cstp {
 
@@ -253,8 +259,14 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 #if CSTP_PIN_PREFETCH
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
 #endif
+#if CSTP_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
+#if CSTP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if CSTP_PIN_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -305,7 +317,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // K2: weight gradient.  dwp[m][j] += sum_{n in split} dy[m][n] * xcol[j][n],  j = tap*Cp + c
 // ------------------------------------------------------------------------------------------
-template <int MT, bool STRADDLE, bool VEC4>
+template <int MT, bool STRADDLE, bool VEC4, int BKN>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
          int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
@@ -313,9 +325,12 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
   // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
   // while the current one is multiplied (LDS double buffered, one barrier per tile).
-  constexpr int BM = 32 * MT, BJ = 128, BKN = 32, LD = BKN + 1;
-  constexpr int AR = VEC4 ? MT : BM / 8;   // dy loads per thread (float4 of 4 positions, or single floats)
-  constexpr int BR = 16;        // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
+  constexpr int BM = 32 * MT, BJ = 128, LD = BKN + 1;
+  constexpr int ARS = 256 / BKN;             // scalar A loader: dy-row step between a thread's loads
+  constexpr int A4S = 1024 / BKN;            // float4 A loader: dy-row step
+  constexpr int BSUB = 64 / BKN;             // B loader: xcol rows covered by one wave instruction
+  constexpr int AR = VEC4 ? BM / A4S : BM / ARS;   // dy loads per thread (float4 of 4 positions, or single floats)
+  constexpr int BR = 32 / BSUB;              // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
 
@@ -355,15 +370,16 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int lrow = lane >> 5, lcol = lane & 31;
-  const int pos = t & 31, arow = t >> 5;     // scalar A loader: position within the tile, first dy row
-  const int q4 = t & 7, arow4 = t >> 3;      // float4 A loader: which 4 positions, first dy row (stride 32)
-  float va[VEC4 ? 4 * MT : AR], vb[BR];
+  const int pos = t % BKN, arow = t / BKN;   // scalar A loader: position within the tile, first dy row
+  const int q4 = t % (BKN / 4), arow4 = t / (BKN / 4);   // float4 A loader: which 4 positions, first dy row
+  const int bpos = lane % BKN, bsub = lane / BKN;        // B loader: position, first xcol row of the wave's 32
+  float va[VEC4 ? 4 * AR : AR], vb[BR];
   bool a_valid4 = false;
   bool a_valid = false;                       // this thread's position exists (tile-level)
   unsigned b_mask = 0;                        // per-row validity of the gathered x elements
 
   auto load_tile = [&](int kti) __attribute__((always_inline)) {
-    const int n = kti * BKN + pos;
+    const int n = kti * BKN + (VEC4 ? bpos : pos);   // VEC4: coordinates serve the B gather only
     const bool nvalid = n < npos;
     int b = 0, sp = 0, od = 0, oh = 0, ow = 0;
     if (nvalid) {
@@ -381,8 +397,8 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       a_valid4 = v4;
       const size_t ab4 = (size_t)b4 * g.M * S + sp4;
 #pragma unroll
-      for (int r = 0; r < MT; ++r) {
-        const int m = m0 + arow4 + 32 * r;
+      for (int r = 0; r < AR; ++r) {
+        const int m = m0 + arow4 + A4S * r;
         const float4 v = *reinterpret_cast<const float4*>(dy + ((v4 && m < g.M) ? ab4 + (size_t)m * S : 0));
         va[4 * r + 0] = v.x; va[4 * r + 1] = v.y; va[4 * r + 2] = v.z; va[4 * r + 3] = v.w;
       }
@@ -390,7 +406,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       const size_t ab = (size_t)b * g.M * S + sp;
 #pragma unroll
       for (int r = 0; r < AR; ++r) {            // unconditional clamped loads, zero selected at store time
-        const int m = m0 + arow + 8 * r;
+        const int m = m0 + arow + ARS * r;
         va[r] = dy[(nvalid && m < g.M) ? ab + (size_t)m * S : 0];
       }
     }
@@ -404,7 +420,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
         const int toff = id * HWs + ih * g.Ws + iw;
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
-          const int c = cw0 + lrow + 2 * r;
+          const int c = cw0 + bsub + BSUB * r;
           const bool ok = v0 && c < g.Cs;
           vb[r] = x[ok ? xb + (size_t)c * DHWs + toff : 0];
           b_mask |= (ok ? 1u : 0u) << r;
@@ -412,7 +428,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       } else {
 #pragma unroll
         for (int r = 0; r < BR; ++r) {
-          const int j = jw0 + lrow + 2 * r;
+          const int j = jw0 + bsub + BSUB * r;
           const int jc = j < Jtot ? j : 0;
           const int tp = jc / g.Cp, c = jc - tp * g.Cp;
           const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
@@ -428,8 +444,8 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     if (VEC4) {
 #pragma unroll
-      for (int r = 0; r < MT; ++r) {
-        const int ml = arow4 + 32 * r;
+      for (int r = 0; r < AR; ++r) {
+        const int ml = arow4 + A4S * r;
         const bool ok = a_valid4 && (m0 + ml) < g.M;
 #pragma unroll
         for (int i = 0; i < 4; ++i) As[buf][ml * LD + 4 * q4 + i] = ok ? va[4 * r + i] : 0.f;
@@ -437,14 +453,14 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     } else {
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
-        const int ml = arow + 8 * r;
+        const int ml = arow + ARS * r;
         As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
       }
     }
     if (wave_active) {
 #pragma unroll
       for (int r = 0; r < BR; ++r)
-        Bs[buf][(wave * 32 + lrow + 2 * r) * LD + lcol] = ((b_mask >> r) & 1u) ? vb[r] : 0.f;
+        Bs[buf][(wave * 32 + bsub + BSUB * r) * LD + bpos] = ((b_mask >> r) & 1u) ? vb[r] : 0.f;
     }
   };
 
@@ -472,8 +488,14 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #if CSTP_PIN_PREFETCH
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
 #endif
+#if CSTP_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
+#if CSTP_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if CSTP_PIN_PREFETCH
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -604,11 +626,11 @@ static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const fl
 #undef CSTP_K1
 }
 
-template <bool STRADDLE, bool VEC4>
+template <bool STRADDLE, bool VEC4, int BKN>
 static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* dy, const float* x, float* dwp,
                       int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit) {
 #define CSTP_K2(MT_) \
-  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per, ntm, ntj, nsplit)
+  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per, ntm, ntj, nsplit)
   switch (mt) {
     case 1: CSTP_K2(1); break;
     case 2: CSTP_K2(2); break;
@@ -711,21 +733,22 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
   const int npos = d.n * p.Do * p.Ho * p.Wo;
-  const int kt_total = cdiv(npos, 32);
+  const int bkn = CSTP_K2_BKN;
+  const int kt_total = cdiv(npos, bkn);
   const int ntm = cdiv(d.k, 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
   int splits = cdiv(1024, ntm * ntj);
-  if (splits > cdiv(kt_total, 8)) splits = cdiv(kt_total, 8);
+  if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
   splits = cdiv(kt_total, kt_per);
   dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
   const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
   if (p.w_straddle) {
-    if (v4) launch_k2<true, true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else launch_k2<true, false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    if (v4) launch_k2<true, true, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else launch_k2<true, false, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
   } else {
-    if (v4) launch_k2<false, true>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else launch_k2<false, false>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    if (v4) launch_k2<false, true, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else launch_k2<false, false, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
   }
   CSTP_LAUNCH_CHECK();
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
