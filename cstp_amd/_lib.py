@@ -11,13 +11,18 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(ctypes.Structure):
     """struct cstp_conv_desc (include/cstp_hip.h)."""
     _fields_ = [(n, c_int32) for n in
                 ("n", "c", "d", "h", "w", "k", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class InAffine(ctypes.Structure):
+    """struct cstp_in_affine: BN(+ReLU) folded into a convolution's gather."""
+    _fields_ = [("scale_shift", c_void_p), ("groups", c_int32), ("relu", c_int32)]
 
 
 class CstpError(RuntimeError):
@@ -32,13 +37,15 @@ SIGNATURES = {
     "cstp_abi_version": (c_int32, []),
     "cstp_last_error": (c_char_p, []),
     "cstp_conv3d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "cstp_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t]),
+    "cstp_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, POINTER(InAffine), _P, _P, c_size_t]),
     "cstp_conv3d_backward_data": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
-    "cstp_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t]),
     "cstp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "cstp_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                         c_float, c_float, c_int32, _P, c_size_t]),
-    "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+    "cstp_bn_stats_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float,
+                                      c_float, _P, c_size_t]),
+    "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, _P, c_size_t]),
     "cstp_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),

@@ -28,12 +28,17 @@ template <int MODE, bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                  const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int npg,
-                 int c, int s, int nsplit, int relu) {
+                 int c, int s, int nsplit, int relu, const float2* __restrict__ ss) {
   __shared__ double sm[16];
   const int ch = blockIdx.x, grp = blockIdx.y / nsplit, j = blockIdx.y - grp * nsplit;
   double a0 = 0.0, a1 = 0.0;
   float mu = 0.f, is = 0.f;
   if (MODE == 1) { mu = mean[grp * c + ch]; is = invstd[grp * c + ch]; }
+  // ReLU mask: sign of the forward OUTPUT y when it was materialised, else recomputed from x with the
+  // (scale, shift) the consumer convolution applied in its gather (fused BN->ReLU->conv)
+  const bool remask = (MODE == 1) && relu && (y == nullptr);
+  float sc = 0.f, sh = 0.f;
+  if (remask) { const float2 t2 = ss[grp * c + ch]; sc = t2.x; sh = t2.y; }
   for (int rr = j; rr < npg; rr += nsplit) {
     const int row = grp * npg + rr;
     const size_t base = ((size_t)row * c + ch) * s;
@@ -49,7 +54,10 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
           a1 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         } else {
           float4 g = gp[i];
-          if (relu) {
+          if (remask) {
+            g.x = (v.x * sc + sh) > 0.f ? g.x : 0.f; g.y = (v.y * sc + sh) > 0.f ? g.y : 0.f;
+            g.z = (v.z * sc + sh) > 0.f ? g.z : 0.f; g.w = (v.w * sc + sh) > 0.f ? g.w : 0.f;
+          } else if (relu) {
             const float4 o = yp[i];
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
@@ -66,7 +74,8 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
           a0 += (double)v; a1 += (double)v * v;
         } else {
           float g = dy[base + i];
-          if (relu && !(y[base + i] > 0.f)) g = 0.f;
+          if (remask) { if (!((v * sc + sh) > 0.f)) g = 0.f; }
+          else if (relu && !(y[base + i] > 0.f)) g = 0.f;
           a0 += (double)g; a1 += (double)(g * ((v - mu) * is));
         }
       }
@@ -84,7 +93,8 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
 __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int c, int groups, int nsplit, double count,
-                                       float eps, float momentum) {
+                                       float eps, float momentum, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float2* __restrict__ ss) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   float rm = 0.f, rv = 0.f;
@@ -97,7 +107,12 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
     double var = s1 / count - mu * mu;
     if (var < 0.0) var = 0.0;
     save_mean[g * c + ch] = (float)mu;
-    save_invstd[g * c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+    const float isf = (float)(1.0 / sqrt(var + (double)eps));
+    save_invstd[g * c + ch] = isf;
+    if (ss != nullptr) {                 // the affine form bn_apply uses: y = x*scale + shift
+      const float scl = isf * gamma[ch];
+      ss[g * c + ch] = make_float2(scl, beta[ch] - (float)mu * scl);
+    }
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
     rv = (float)((1.0 - momentum) * rv + momentum * unb);
@@ -163,7 +178,9 @@ __global__ void __launch_bounds__(256)
 bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                     const float* __restrict__ gsum, float* __restrict__ dx,
-                    float* __restrict__ dres, size_t total, int c, int s, int npg, float inv_count, int relu) {
+                    float* __restrict__ dres, size_t total, int c, int s, int npg, float inv_count, int relu,
+                    const float2* __restrict__ ss) {
+  const bool remask = relu && (y == nullptr);
   constexpr int W = VEC4 ? 4 : 1;
   const size_t nvec = total / W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
@@ -174,10 +191,15 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
     const float mu = mean[gc], is = invstd[gc];
     const float k = gamma[ch] * is;
     const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
+    float sc = 0.f, sh = 0.f;
+    if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
     if (VEC4) {
       const float4 v = reinterpret_cast<const float4*>(x)[i];
       float4 g = reinterpret_cast<const float4*>(dy)[i];
-      if (relu) {
+      if (remask) {
+        g.x = (v.x * sc + sh) > 0.f ? g.x : 0.f; g.y = (v.y * sc + sh) > 0.f ? g.y : 0.f;
+        g.z = (v.z * sc + sh) > 0.f ? g.z : 0.f; g.w = (v.w * sc + sh) > 0.f ? g.w : 0.f;
+      } else if (relu) {
         const float4 o = reinterpret_cast<const float4*>(y)[i];
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
@@ -191,7 +213,8 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
       reinterpret_cast<float4*>(dx)[i] = o;
     } else {
       float g = dy[e];
-      if (relu && !(y[e] > 0.f)) g = 0.f;
+      if (remask) { if (!((x[e] * sc + sh) > 0.f)) g = 0.f; }
+      else if (relu && !(y[e] > 0.f)) g = 0.f;
       if (dres != nullptr) dres[e] = g;
       dx[e] = k * (g - mb - (x[e] - mu) * is * mg);
     }
@@ -305,11 +328,11 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   const int ns = bn_nsplit(npg, c);
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0);
-  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0);
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
-                     running_var, c, groups, ns, (double)npg * s, eps, momentum);
+                     running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta, nullptr);
   CSTP_LAUNCH_CHECK();
   const size_t total = (size_t)n * c * s;
   if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);
@@ -318,11 +341,37 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   return 0;
 }
 
+extern "C" int cstp_bn_stats_train(void* stream, const float* x, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* save_mean, float* save_invstd, float* scale_shift, int32_t n,
+                                   int32_t c, int32_t s, int32_t groups, float eps, float momentum, void* ws,
+                                   size_t ws_bytes) {
+  CSTP_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale_shift, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 1 && groups > 0 && (n % groups) == 0, "bad shape");
+  CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int npg = n / groups;
+  double* part = reinterpret_cast<double*>(ws);
+  const int ns = bn_nsplit(npg, c);
+  const dim3 rgrid(c, groups * ns);
+  if ((s % 4) == 0) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
+                     running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
+                     reinterpret_cast<float2*>(scale_shift));
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
-                                const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
-                                float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups, int32_t relu,
-                                void* ws, size_t ws_bytes) {
-  CSTP_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
+                                const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
+                                float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s,
+                                int32_t groups, int32_t relu, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
+  CSTP_REQUIRE(y != nullptr || !relu || scale_shift != nullptr, "ReLU mask needs y or scale_shift");
+  CSTP_REQUIRE(y != nullptr || s > 1, "BatchNorm1d backward needs y");
+  const float2* ss2 = reinterpret_cast<const float2*>(scale_shift);
   CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
   const int npg = n / groups;
   hipStream_t st = as_stream(stream);
@@ -339,15 +388,15 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
                                          align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu);
-  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu);
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
+  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
   CSTP_LAUNCH_CHECK();
   const size_t total = (size_t)n * c * s;
   const float inv_count = (float)(1.0 / ((double)npg * s));
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu);
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu, ss2);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu, ss2);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

@@ -81,10 +81,15 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // WM = waves along M (1, 2 or 4), 4/WM waves along N: block tile (32*MT*WM) x (32*4/WM).  The wide
 // 128-column tile (WM = 1) serves the big early layers; the 64- and 32-column tiles keep >= 256
 // blocks in flight on the deep layers, whose position count is small (2B*2*7*7) but K is long.
-template <int MT, int WM, bool DGRAD, bool STRADDLE>
+// XFORM: the gathered operand is transformed on the fly, z = act(x * scale[g][c] + shift[g][c]) with a
+// per-(BN group, channel) table -- i.e. the train-mode BatchNorm(+ReLU) that precedes this convolution
+// is applied inside its gather and the normalised tensor never exists in HBM.  Zero padding applies
+// to z (masked elements stay exactly 0).
+template <int MT, int WM, bool DGRAD, bool STRADDLE, bool XFORM>
 __global__ void __launch_bounds__(256)
 igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ src, const float* __restrict__ bias,
-         float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
+         float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float2* __restrict__ in_ss, int in_npg,
+         int in_relu) {
   constexpr int WN = 4 / WM;
   constexpr int BM = 32 * MT * WM, BN = 32 * WN, BK = 16;
   constexpr int BR = BK * BN / 256;      // B-tile rows gathered per thread (8 / 4 / 2)
@@ -136,6 +141,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     npd = n % Dp; nb = n / Dp;
   }
   const size_t src_b = (size_t)nb * g.Cs * DHWs;
+  const int ss_b = XFORM ? (nb / in_npg) * g.Cs : 0;   // row of the (scale, shift) table for this sample's BN group
 
   f32x16 acc[MT];
 #pragma unroll
@@ -221,7 +227,14 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         off = src_b + (size_t)c * DHWs + toff;
       }
       const float v = src[ok ? off : 0];
-      rb[r] = ok ? v : 0.f;
+      if (XFORM) {
+        const float2 ss = in_ss[ss_b + (ok ? c0 + kr : 0)];
+        float z = v * ss.x + ss.y;
+        if (in_relu) z = fmaxf(z, 0.f);
+        rb[r] = ok ? z : 0.f;
+      } else {
+        rb[r] = ok ? v : 0.f;
+      }
     }
   };
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
@@ -317,10 +330,11 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // K2: weight gradient.  dwp[m][j] += sum_{n in split} dy[m][n] * xcol[j][n],  j = tap*Cp + c
 // ------------------------------------------------------------------------------------------
-template <int MT, bool STRADDLE, bool VEC4, int BKN>
+template <int MT, bool STRADDLE, bool VEC4, int BKN, bool XFORM>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
-         int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
+         int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit,
+         const float2* __restrict__ in_ss, int in_npg, int in_groups, int in_relu) {
   // Block tile (32*MT) x 128 outputs; the reduction runs over positions in tiles of 32, staged
   // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
   // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
@@ -333,6 +347,9 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   constexpr int BR = 32 / BSUB;              // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
+  // XFORM: (scale, shift) of this block's 128 gathered columns for up to 4 BN groups; the x operand is
+  // turned into z = act(x*scale + shift) as it is staged (see igemm_k1)
+  __shared__ float2 Ss[XFORM ? 4 * BJ : 1];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // XCD-aware order (blocks b, b+8 share an L2): the ntj column tiles that read the same dY panel of
@@ -370,6 +387,17 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int lrow = lane >> 5, lcol = lane & 31;
+  if (XFORM) {
+    for (int i = t; i < in_groups * BJ; i += 256) {
+      const int gi = i / BJ, jj = i - gi * BJ;
+      const int j = j0 + jj;
+      const int c = j < Jtot ? (j % g.Cp) : g.Cs;
+      Ss[i] = c < g.Cs ? in_ss[gi * g.Cs + c] : make_float2(0.f, 0.f);
+    }
+    // visible to every wave after the first __syncthreads() below (before any tile is staged? no:
+    // the prologue stages tile 0 first) -> explicit barrier
+    __syncthreads();
+  }
   const int pos = t % BKN, arow = t / BKN;   // scalar A loader: position within the tile, first dy row
   const int q4 = t % (BKN / 4), arow4 = t / (BKN / 4);   // float4 A loader: which 4 positions, first dy row
   const int bpos = lane % BKN, bsub = lane / BKN;        // B loader: position, first xcol row of the wave's 32
@@ -377,6 +405,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   bool a_valid4 = false;
   bool a_valid = false;                       // this thread's position exists (tile-level)
   unsigned b_mask = 0;                        // per-row validity of the gathered x elements
+  int b_grp = 0;                              // BN group of this thread's position (XFORM)
 
   auto load_tile = [&](int kti) __attribute__((always_inline)) {
     const int n = kti * BKN + (VEC4 ? bpos : pos);   // VEC4: coordinates serve the B gather only
@@ -411,6 +440,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       }
     }
     b_mask = 0;
+    if (XFORM) b_grp = b / in_npg;
     if (wave_active) {
       const size_t xb = (size_t)b * g.Cs * DHWs;
       if (!STRADDLE) {
@@ -459,8 +489,15 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     }
     if (wave_active) {
 #pragma unroll
-      for (int r = 0; r < BR; ++r)
-        Bs[buf][(wave * 32 + bsub + BSUB * r) * LD + bpos] = ((b_mask >> r) & 1u) ? vb[r] : 0.f;
+      for (int r = 0; r < BR; ++r) {
+        float v = vb[r];
+        if (XFORM) {
+          const float2 ss = Ss[b_grp * BJ + wave * 32 + bsub + BSUB * r];
+          v = v * ss.x + ss.y;
+          if (in_relu) v = fmaxf(v, 0.f);
+        }
+        Bs[buf][(wave * 32 + bsub + BSUB * r) * LD + bpos] = ((b_mask >> r) & 1u) ? v : 0.f;
+      }
     }
   };
 
@@ -605,11 +642,12 @@ static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   return align_up(m * sizeof(float), 256);
 }
 
-template <bool DGRAD, bool STRADDLE>
+template <bool DGRAD, bool STRADDLE, bool XFORM>
 static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
-                      const float* bias, float* out, int ntx, int ntm) {
-#define CSTP_K1(MT_, WM_) \
-  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm)
+                      const float* bias, float* out, int ntx, int ntm, const float2* in_ss, int in_npg, int in_relu) {
+#define CSTP_K1(MT_, WM_)                                                                                      \
+  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE, XFORM>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, \
+                     ntm, in_ss, in_npg, in_relu)
   if (tl.wm == 1) {
     switch (tl.mt) {
       case 1: CSTP_K1(1, 1); break;
@@ -626,11 +664,13 @@ static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const fl
 #undef CSTP_K1
 }
 
-template <bool STRADDLE, bool VEC4, int BKN>
+template <bool STRADDLE, bool VEC4, int BKN, bool XFORM>
 static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* dy, const float* x, float* dwp,
-                      int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit) {
-#define CSTP_K2(MT_) \
-  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, kt_total, kt_per, ntm, ntj, nsplit)
+                      int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit, const float2* in_ss,
+                      int in_npg, int in_groups, int in_relu) {
+#define CSTP_K2(MT_)                                                                                              \
+  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN, XFORM>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, \
+                     kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu)
   switch (mt) {
     case 1: CSTP_K2(1); break;
     case 2: CSTP_K2(2); break;
@@ -639,6 +679,18 @@ static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const flo
     default: CSTP_K2(5); break;
   }
 #undef CSTP_K2
+}
+
+// optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
+struct InAffine { const float2* ss; int npg, groups, relu; };
+static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
+  o.ss = nullptr; o.npg = 1; o.groups = 1; o.relu = 0;
+  if (a == nullptr || a->scale_shift == nullptr) return 0;
+  if (a->groups < 1 || a->groups > 4 || (d.n % a->groups) != 0) return fail("in_affine: bad group count%s", "");
+  if (d.c < 8) return fail("in_affine: not supported on the <8-channel (stem) path%s", "");
+  o.ss = reinterpret_cast<const float2*>(a->scale_shift);
+  o.groups = a->groups; o.npg = d.n / a->groups; o.relu = a->relu ? 1 : 0;
+  return 0;
 }
 
 static int pack_grid(size_t total) {
@@ -657,14 +709,15 @@ extern "C" size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
 }
 
 extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
-                                   const float* bias, float* y, void* ws, size_t ws_bytes) {
+                                   const float* bias, const cstp_in_affine* in_affine, float* y, void* ws,
+                                   size_t ws_bytes) {
   CSTP_REQUIRE(desc && x && w && y && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
   const cstp_conv_desc& d = *desc;
-  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
-               "tensor too large for 32-bit plane offsets");
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
+               "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
@@ -679,8 +732,11 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   const int f_bm = 32 * p.f_t.mt * p.f_t.wm, f_bn = 32 * (4 / p.f_t.wm);
   const int ntx = cdiv(npos, f_bn), ntm = cdiv(d.k, f_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
-  if (p.f_straddle) launch_k1<false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm);
-  else launch_k1<false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm);
+  InAffine ia;
+  if (parse_in_affine(in_affine, d, ia)) return 1;
+  if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
+  else if (ia.ss) launch_k1<false, false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, ia.ss, ia.npg, ia.relu);
+  else launch_k1<false, false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -692,8 +748,8 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
   const cstp_conv_desc& d = *desc;
-  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
-               "tensor too large for 32-bit plane offsets");
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
+               "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
   const size_t tot = (size_t)p.d_Kp * p.d_Mp;
@@ -709,20 +765,21 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   const int d_bm = 32 * p.d_t.mt * p.d_t.wm, d_bn = 32 * (4 / p.d_t.wm);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
-  launch_k1<true, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm);
+  launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x, const float* dy,
-                                           float* dw, void* ws, size_t ws_bytes) {
+extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x,
+                                           const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
+                                           size_t ws_bytes) {
   CSTP_REQUIRE(desc && x && dy && dw && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
   const cstp_conv_desc& d = *desc;
-  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 31) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 31),
-               "tensor too large for 32-bit plane offsets");
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
+               "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* dwp = reinterpret_cast<float*>(ws);
   const size_t slab = (size_t)d.k * p.w_Jp * sizeof(float);
@@ -743,13 +800,20 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   splits = cdiv(kt_total, kt_per);
   dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
   const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+  InAffine ia;
+  if (parse_in_affine(in_affine, d, ia)) return 1;
+#define CSTP_K2_ARGS p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, ia.ss, ia.npg, ia.groups, ia.relu
   if (p.w_straddle) {
-    if (v4) launch_k2<true, true, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else launch_k2<true, false, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    if (v4) launch_k2<true, true, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
+    else launch_k2<true, false, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
+  } else if (ia.ss) {
+    if (v4) launch_k2<false, true, CSTP_K2_BKN, true>(CSTP_K2_ARGS);
+    else launch_k2<false, false, CSTP_K2_BKN, true>(CSTP_K2_ARGS);
   } else {
-    if (v4) launch_k2<false, true, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else launch_k2<false, false, CSTP_K2_BKN>(p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    if (v4) launch_k2<false, true, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
+    else launch_k2<false, false, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
   }
+#undef CSTP_K2_ARGS
   CSTP_LAUNCH_CHECK();
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp);

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, check
+from ._lib import ConvDesc, InAffine, check
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -90,7 +90,7 @@ class _Conv3d(torch.autograd.Function):
         timed = tm is not None and tm.match("conv3d_forward", desc)
         if timed:
             tm.start()
-        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(),
+        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None, y.data_ptr(),
                                       ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
         if timed:
             tm.stop()
@@ -114,8 +114,8 @@ class _Conv3d(torch.autograd.Function):
                                                 ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                                  ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_weight")
+            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
+                                                  dw.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_weight")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, k = dy.shape[0], dy.shape[1]
             s = dy.numel() // (n * k)
@@ -182,8 +182,8 @@ class _BNAct(torch.autograd.Function):
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)
         ws = _workspace(x.device, nbytes)
         check(lib.cstp_bn_backward(_stream(), x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                   invstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n, c, s,
-                                   ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
+                                   invstd.data_ptr(), None, dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
+                                   c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
@@ -193,6 +193,78 @@ def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual
     that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
     return _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
                         int(groups))
+
+
+# ----------------------------------------------------------------------------------------------
+# fused  BatchNorm(train) -> ReLU -> conv3d : the normalised tensor never exists in HBM
+# ----------------------------------------------------------------------------------------------
+class _BNReluConv3d(torch.autograd.Function):
+    """y = conv3d(relu(batch_norm_train(x)), w).  Forward: one statistics pass over x, then the convolution
+    applies x*scale+shift (+ReLU) inside its gather.  Backward: data gradient of the convolution, weight gradient
+    with the same transform recomputed in ITS gather, then the BN backward with the ReLU mask recomputed from x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, w, stride, padding, groups, relu, eps, momentum):
+        lib = _lib.load()
+        x = _req(x, "bn_relu_conv3d input")
+        gamma, beta, w = _req(gamma, "bn weight"), _req(beta, "bn bias"), _req(w, "conv weight")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        if groups < 1 or groups > 4 or n % groups != 0:
+            raise _lib.CstpError("batch of %d rows cannot be split into %d BN groups" % (n, groups))
+        mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, lib.cstp_bn_workspace_bytes(n, c, s, groups))
+        check(lib.cstp_bn_stats_train(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
+                                      _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), n, c, s, groups,
+                                      eps, momentum, ws.data_ptr(), ws.numel()), "cstp_bn_stats_train")
+        desc = _desc(x.shape, w.shape, stride, padding)
+        y = torch.empty(conv_out_shape(x.shape, w.shape, stride, padding), dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)))
+        aff = InAffine(ss.data_ptr(), groups, 1 if relu else 0)
+        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
+                                      y.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
+        ctx.save_for_backward(x, gamma, mean, invstd, ss, w)
+        ctx.desc, ctx.groups, ctx.relu = desc, groups, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, invstd, ss, w = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _req(dy, "bn_relu_conv3d grad_output")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        ws = _workspace(x.device, max(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)),
+                                      lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)))
+        dw = None
+        if ctx.needs_input_grad[5]:
+            dw = torch.empty_like(w)
+            aff = InAffine(ss.data_ptr(), ctx.groups, 1 if ctx.relu else 0)
+            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), ctypes.byref(aff),
+                                                  dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel()),
+                  "cstp_conv3d_backward_weight")
+        dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dz = torch.empty_like(x)     # gradient w.r.t. the (never materialised) normalised activation
+            check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(),
+                                                ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
+            dx = torch.empty_like(x)
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+            check(lib.cstp_bn_backward(_stream(), x.data_ptr(), None, dz.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                       invstd.data_ptr(), ss.data_ptr(), dx.data_ptr(), None, dgamma.data_ptr(),
+                                       dbeta.data_ptr(), n, c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()),
+                  "cstp_bn_backward")
+        return dx, dgamma, dbeta, None, None, dw, None, None, None, None, None, None
+
+
+def bn_relu_conv3d(x, gamma, beta, running_mean, running_var, w, stride=1, padding=0, groups=1, relu=True, eps=BN_EPS,
+                   momentum=BN_MOMENTUM):
+    """conv3d(act(batch_norm_train(x)), w) with the BN apply fused into the convolution's gather."""
+    return _BNReluConv3d.apply(x, gamma, beta, running_mean, running_var, w, _triple(stride), _triple(padding), int(groups),
+                               bool(relu), float(eps), float(momentum))
 
 
 # ----------------------------------------------------------------------------------------------

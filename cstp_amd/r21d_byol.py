@@ -9,13 +9,15 @@ runs in the HIP kernels of libcstp_hip.so (cstp_amd.ops).  Differences from the 
 all additive:
   * ``layer_sizes`` is a constructor argument of R21DBYOL (the reference hard-codes (1,1,1,1),
     :268-269) so --model_depth 18/34 means R(2+1)D-18/34 (SURVEY 5.6);
-  * BN+ReLU and BN+residual+ReLU are single fused ops;
+  * BN+ReLU and BN+residual+ReLU are single kernels; optionally (CSTP_FUSE_BN=1) a BN+ReLU that feeds exactly
+    one convolution is folded into that convolution's gather and never materialised;
   * parameters live in flat HBM arenas (``flatten_parameters``) so EMA / clip / SGD are one
     streaming kernel each instead of ~80 tiny ones (:331-337 rebinding .data per tensor).
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -24,6 +26,8 @@ import torch.nn as nn
 from . import ops
 
 LAYER_SIZES = {1: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+# Fold BN+ReLU into the consumer convolution's gather (ops.bn_relu_conv3d) instead of materialising it.
+FUSE_BN_INTO_CONV = os.environ.get("CSTP_FUSE_BN", "0") == "1"
 
 
 def layer_sizes_for_depth(depth: int) -> Tuple[int, int, int, int]:
@@ -75,6 +79,17 @@ class _BatchNorm(nn.Module):
                                self.momentum, groups)
         if not getattr(self, "_nbt_in_arena", False):
             self.num_batches_tracked += groups   # else: one add per net per forward, see R21DBYOL.forward
+        return y
+
+    def relu_then(self, conv, x, groups=1):
+        """conv(relu(self(x))) with this BN's apply+ReLU folded into ``conv``'s gather: only the statistics
+        pass touches x before the convolution, and relu(bn(x)) is never written to HBM."""
+        if not self.training:
+            raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
+        y = ops.bn_relu_conv3d(x, self.weight, self.bias, self.running_mean, self.running_var, conv.weight, conv.stride,
+                               conv.padding, groups, True, self.eps, self.momentum)
+        if not getattr(self, "_nbt_in_arena", False):
+            self.num_batches_tracked += groups
         return y
 
 
@@ -141,7 +156,18 @@ class SpatioTemporalConv(nn.Module):
         self.temporal_conv = Conv3d(intermed_channels, out_channels, (kernel_size[0], 1, 1), stride=(stride[0], 1, 1),
                                     padding=(padding[0], 0, 0), bias=bias)
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, pre_bn=None):
+        """temporal_conv(relu(bn(spatial_conv(x)))) (r21d_byol.py:94-97).  ``pre_bn``: the BatchNorm whose
+        apply+ReLU precedes this module in the block (bn1 -> relu1 -> conv2, :142-143).
+        With FUSE_BN_INTO_CONV each BN+ReLU is folded into the following convolution's gather (the normalised
+        tensor is never written: -36 % BN traffic, -7 ms/step of BN kernels, -7 GB of activations at cfg2) --
+        but the per-element affine costs the MFMA kernels' gather more than the two HBM passes it removes
+        (+8 ms/step on MI355X, profiles/r01), so the default materialises BN outputs."""
+        if FUSE_BN_INTO_CONV:
+            x = self.spatial_conv(x) if pre_bn is None else pre_bn.relu_then(self.spatial_conv, x, groups)
+            return self.bn.relu_then(self.temporal_conv, x, groups)
+        if pre_bn is not None:
+            x = pre_bn(x, relu=True, groups=groups)
         x = self.bn(self.spatial_conv(x), relu=True, groups=groups)
         return self.temporal_conv(x)
 
@@ -164,8 +190,7 @@ class SpatioTemporalResBlock(nn.Module):
         self.outrelu = ReLU()
 
     def forward(self, x, groups=1):
-        res = self.bn1(self.conv1(x, groups), relu=True, groups=groups)
-        res = self.conv2(res, groups)
+        res = self.conv2(self.conv1(x, groups), groups, pre_bn=self.bn1)   # conv2(relu1(bn1(conv1(x))))
         if self.downsample:
             x = self.downsamplebn(self.downsampleconv(x, groups), groups=groups)
         # relu(x + bn2(res)) as one kernel (r21d_byol.py:143,148)

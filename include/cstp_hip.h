@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 2
+#define CSTP_ABI_VERSION 3
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -40,20 +40,34 @@ typedef struct cstp_conv_desc {
   int32_t pt, ph, pw;    /* zero padding                       */
 } cstp_conv_desc;
 
+/* Optional input transform fused into a convolution's gather: z = act(x * scale + shift) with one
+ * (scale, shift) pair per (BN group, input channel) -- the train-mode BatchNorm (+ReLU) that precedes the
+ * convolution in the reference (r21d_byol.py:94-97 `temporal_conv(relu(bn(spatial_conv(x))))`, :142-143
+ * `conv2(relu1(bn1(.)))`) applied on the fly, so the normalised tensor is never written to HBM.
+ * scale_shift: float[groups][c][2] as produced by cstp_bn_stats_train; zero padding applies to z. */
+typedef struct cstp_in_affine {
+  const float* scale_shift;
+  int32_t groups; /* 1..4, must divide desc->n */
+  int32_t relu;   /* non-zero: z = max(z, 0) */
+} cstp_in_affine;
+
 int cstp_abi_version(void);
 const char* cstp_last_error(void);
 
 /* ---- convolution (F.conv3d / F.linear and their autograd) ------------------------------- */
 size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc);
-/* y[n][k][do][ho][wo] = conv3d(x, w) (+ bias[k] when bias != NULL).  w is [k][c][kt][kh][kw]. */
+/* y[n][k][do][ho][wo] = conv3d(T(x), w) (+ bias[k] when bias != NULL).  w is [k][c][kt][kh][kw].
+ * T = identity when in_affine == NULL, else the fused BN(+ReLU) input transform above. */
 int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
-                        const float* bias, float* y, void* ws, size_t ws_bytes);
+                        const float* bias, const cstp_in_affine* in_affine, float* y, void* ws, size_t ws_bytes);
 /* dx = conv3d input gradient (aten::convolution_backward, input mask). */
 int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
                               float* dx, void* ws, size_t ws_bytes);
-/* dw = conv3d weight gradient, [k][c][kt][kh][kw] (aten::convolution_backward, weight mask). */
-int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x, const float* dy,
-                                float* dw, void* ws, size_t ws_bytes);
+/* dw = conv3d weight gradient w.r.t. T(x), [k][c][kt][kh][kw] (aten::convolution_backward, weight mask);
+ * in_affine as in the forward call (NULL = identity). */
+int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x,
+                                const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
+                                size_t ws_bytes);
 
 /* ---- BatchNorm3d / BatchNorm1d in TRAIN mode, fused with the residual add and ReLU that follow
  *      it (r21d_byol.py:83-84,133-134,138-139,148,199-200,216; Projector/Predictor/heads BN1d).
@@ -68,12 +82,19 @@ int cstp_bn_forward_train(void* stream, const float* x, const float* residual, f
                           const float* beta, float* running_mean, float* running_var, float* save_mean,
                           float* save_invstd, int32_t n, int32_t c, int32_t s, int32_t groups, float eps,
                           float momentum, int32_t relu, void* ws, size_t ws_bytes);
-/* Backward of the fused op.  y is the forward OUTPUT (its sign is the ReLU mask).  dresidual may be
- * NULL.  dgamma/dbeta: [c], summed over the groups (they share the affine parameters). */
+/* Statistics only: save_mean/save_invstd [groups][c], running stats update, and the affine table
+ * scale_shift float[groups][c][2] = (invstd*gamma, beta - mean*invstd*gamma) that a consumer convolution
+ * applies in its gather (cstp_in_affine) -- the BN output itself is never materialised. */
+int cstp_bn_stats_train(void* stream, const float* x, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* save_mean, float* save_invstd, float* scale_shift, int32_t n,
+                        int32_t c, int32_t s, int32_t groups, float eps, float momentum, void* ws, size_t ws_bytes);
+/* Backward of the fused op.  y is the forward OUTPUT (its sign is the ReLU mask); when the output was
+ * never materialised (cstp_bn_stats_train + cstp_in_affine) pass y = NULL and the scale_shift table and the
+ * mask is recomputed from x.  dresidual may be NULL.  dgamma/dbeta: [c], summed over the groups. */
 int cstp_bn_backward(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
-                     const float* save_mean, const float* save_invstd, float* dx, float* dresidual,
-                     float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups, int32_t relu,
-                     void* ws, size_t ws_bytes);
+                     const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
+                     float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
+                     int32_t relu, void* ws, size_t ws_bytes);
 
 /* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
 int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);

@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu():
     assert lib.cstp_conv3d_workspace_bytes(ctypes.byref(bad)) == 0
     ok = _lib.ConvDesc(2, 64, 4, 14, 14, 144, 1, 3, 3, 1, 1, 1, 0, 1, 1)
     assert lib.cstp_conv3d_workspace_bytes(ctypes.byref(ok)) >= 9 * 64 * 160 * 4
-    rc = lib.cstp_conv3d_forward(None, ctypes.byref(ok), None, None, None, None, None, 0)
+    rc = lib.cstp_conv3d_forward(None, ctypes.byref(ok), None, None, None, None, None, None, 0)
     assert rc != 0 and b"null argument" in lib.cstp_last_error()
     assert lib.cstp_bn_workspace_bytes(16, 144, 50176, 1) > 0 and lib.cstp_bn_workspace_bytes(15, 144, 50176, 2) == 0
     assert lib.cstp_ntxent_workspace_bytes(32, 512) >= (2 * 32 + 2 * 32 * 32) * 4

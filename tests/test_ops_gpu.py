@@ -146,6 +146,43 @@ def test_bn_groups_equal_successive_calls(shape, relu):
     assert rel_err(xg.grad, x.grad) < TOL and rel_err(gg.grad, gamma.grad) < TOL and rel_err(bg.grad, beta.grad) < TOL
 
 
+FUSED = [
+    # x shape, out channels, kernel, stride, pad, groups   (BN -> ReLU -> conv fused)
+    ((4, 144, 4, 14, 14), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2),     # SpatioTemporalConv.bn -> temporal conv
+    ((4, 64, 4, 14, 14), 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2),      # block bn1 -> conv2.spatial_conv
+    ((2, 230, 8, 7, 7), 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), 1),       # strided temporal
+    ((6, 42, 2, 7, 7), 128, (1, 1, 1), (2, 1, 1), (0, 0, 0), 2),        # shortcut temporal half, s = 98 (scalar paths)
+    ((4, 83, 3, 9, 9), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2),         # ragged channels / extents
+]
+
+
+@pytest.mark.parametrize("xs,k,ks,st,pd,groups", FUSED, ids=lambda v: str(v))
+def test_bn_relu_conv3d_fused(xs, k, ks, st, pd, groups):
+    """Fused BN(train)->ReLU->conv == F.batch_norm per group -> relu -> F.conv3d, forward and all gradients."""
+    from cstp_amd import ops
+    c, half = xs[1], xs[0] // groups
+    x = (_rand(xs, 41) * 1.3 + 0.2).requires_grad_(True)
+    gamma = _rand((c,), 42).requires_grad_(True)
+    beta = (_rand((c,), 43) * 0.2).requires_grad_(True)
+    w = (_rand((k, c) + ks, 44) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    zs = [F.relu(F.batch_norm(x[i * half:(i + 1) * half], rm, rv, gamma, beta, True, 0.1, 1e-5)) for i in range(groups)]
+    y = F.conv3d(torch.cat(zs, 0), w, None, st, pd)
+    dy = _rand(tuple(y.shape), 45)
+    y.backward(dy)
+    xg = x.detach().float().cuda().requires_grad_(True)
+    gg = gamma.detach().float().cuda().requires_grad_(True)
+    bg = beta.detach().float().cuda().requires_grad_(True)
+    wg = w.detach().float().cuda().requires_grad_(True)
+    rmg, rvg = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    yg = ops.bn_relu_conv3d(xg, gg, bg, rmg, rvg, wg, st, pd, groups=groups, relu=True)
+    yg.backward(dy.float().cuda())
+    assert rel_err(yg, y) < TOL and rel_err(rmg, rm) < TOL and rel_err(rvg, rv) < TOL
+    assert rel_err(wg.grad, w.grad) < TOL
+    assert rel_err(xg.grad, x.grad) < TOL
+    assert rel_err(gg.grad, gamma.grad) < TOL and rel_err(bg.grad, beta.grad) < TOL
+
+
 def test_bn_rejects_single_value():
     from cstp_amd import ops, _lib
     x = torch.ones(1, 8, device="cuda")
