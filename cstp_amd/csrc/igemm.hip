@@ -21,6 +21,9 @@
 #ifndef CSTP_SETPRIO
 #define CSTP_SETPRIO 0
 #endif
+#ifndef CSTP_M16
+#define CSTP_M16 1          // 144-row tiles on the 16x16x4 MFMA for 129..144-channel layers
+#endif
 #ifndef CSTP_K2_BKN
 #define CSTP_K2_BKN 32      // positions per weight-gradient reduction tile (32 or 64)
 #endif
@@ -28,6 +31,7 @@
 namespace cstp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Geom {
   int Cs, Ds, Hs, Ws;      // gather source tensor [Nb][Cs][Ds][Hs][Ws]
@@ -85,18 +89,22 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // per-(BN group, channel) table -- i.e. the train-mode BatchNorm(+ReLU) that precedes this convolution
 // is applied inside its gather and the normalised tensor never exists in HBM.  Zero padding applies
 // to z (masked elements stay exactly 0).
-template <int MT, int WM, bool DGRAD, bool STRADDLE, bool XFORM>
+// M16: the rows are covered by MT tiles of 16 (v_mfma_f32_16x16x4_f32, same FLOP rate) instead of 32, so a
+// 144-channel layer (the S1/T1 class, 40 % of all FLOPs) runs an exact 144-row tile instead of padding to 160.
+template <int MT, int WM, bool DGRAD, bool STRADDLE, bool XFORM, bool M16>
 __global__ void __launch_bounds__(256)
 igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ src, const float* __restrict__ bias,
          float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float2* __restrict__ in_ss, int in_npg,
          int in_relu) {
   constexpr int WN = 4 / WM;
-  constexpr int BM = 32 * MT * WM, BN = 32 * WN, BK = 16;
+  constexpr int BM = M16 ? 16 * MT : 32 * MT * WM, BN = 32 * WN, BK = 16;
+  constexpr int BNP = M16 ? BN + 16 : BN;   // LDS row stride of the B tile (16x16x4 reads 2 k-rows per 32 lanes)
   constexpr int BR = BK * BN / 256;      // B-tile rows gathered per thread (8 / 4 / 2)
   constexpr int BRS = 256 / BN;          // row stride between them (2 / 4 / 8)
   static_assert(BM <= 160, "A staging holds at most 3 float4 per thread");
+  static_assert(!M16 || WM == 1, "the 16-row variant uses the 128-column tile");
   __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BNP];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -143,11 +151,16 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   const size_t src_b = (size_t)nb * g.Cs * DHWs;
   const int ss_b = XFORM ? (nb / in_npg) * g.Cs : 0;   // row of the (scale, shift) table for this sample's BN group
 
-  f32x16 acc[MT];
+  f32x16 acc[M16 ? 1 : MT];
+  f32x4 acc16[M16 ? MT : 1][2];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < (M16 ? 1 : MT); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? MT : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc16[i][0][r] = 0.f; acc16[i][1][r] = 0.f; }
 
   constexpr int A_F4 = 4 * BM;                   // float4 per A tile (16 rows x BM/4)
   constexpr int A_ITERS = (A_F4 + 255) / 256;
@@ -242,7 +255,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     if (A_ITERS > 1 && t + 256 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 256) * 4]) = ra1;
     if (A_ITERS > 2 && t + 512 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 512) * 4]) = ra2;
 #pragma unroll
-    for (int r = 0; r < BR; ++r) Bs[buf][(krow0 + BRS * r) * BN + col] = rb[r];
+    for (int r = 0; r < BR; ++r) Bs[buf][(krow0 + BRS * r) * BNP + col] = rb[r];
   };
 
   bool have = first_tile();
@@ -254,7 +267,21 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   while (have) {
     const bool have_next = advance();
     if (have_next) load_tile();
-    {
+    if (M16) {
+      // 16x16x4: lane l feeds A[m = l&15][k = l>>4] and B[k = l>>4][n = l&15]; each wave owns 32 columns = 2 tiles
+      const float* Ab = &As[buf][(lane >> 4) * BM + (lane & 15)];
+      const float* Bb = &Bs[buf][(lane >> 4) * BNP + wn * 32 + (lane & 15)];
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 4) {
+        const float b0 = Bb[kk * BNP], b1 = Bb[kk * BNP + 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = Ab[kk * BM + mt * 16];
+          acc16[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc16[mt][0], 0, 0, 0);
+          acc16[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc16[mt][1], 0, 0, 0);
+        }
+      }
+    } else {
       // operand fragments of k-pair kk+2 are read from LDS while the MFMAs of k-pair kk run
       const float* Ab = &As[buf][lrow * BM + wm * MT * 32 + lcol];
       const float* Bb = &Bs[buf][lrow * BN + wn * 32 + lcol];
@@ -269,20 +296,8 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = Ab[(kk + 2) * BM + mt * 32];
         }
-#if CSTP_PIN_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
-#endif
-#if CSTP_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
-#if CSTP_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if CSTP_PIN_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int mt = 0; mt < (M16 ? 1 : MT); ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
         b_cur = b_nxt;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
@@ -294,6 +309,42 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     have = have_next;
   }
 
+  if (M16) {
+    // C layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
+      if (n >= npos) continue;
+      size_t obase, cstride;
+      if (DGRAD) {
+        int q = n;
+        const int pw = q % Wp; q /= Wp;
+        const int ph = q % Hp; q /= Hp;
+        const int pd = q % Dp; const int b = q / Dp;
+        const int HWf = g.Hp * g.Wp;
+        cstride = (size_t)g.Dp * HWf;
+        obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
+      } else {
+        const int S = Dp * Hp * Wp;
+        const int b = n / S, sp = n - b * S;
+        cstride = (size_t)S;
+        obase = (size_t)b * g.M * cstride + sp;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + mt * 16 + (lane >> 4) * 4 + r;
+          if (m < g.M) {
+            float v = acc16[mt][nt][r];
+            if (bias != nullptr) v += bias[m];
+            out[obase + (size_t)m * cstride] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + lcol;
   if (n < npos) {
@@ -573,14 +624,16 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
   return best;
 }
 
-struct Tile { int mt, wm; };
+struct Tile { int mt, wm, m16; };
+static inline int tile_bm(const Tile& t) { return t.m16 ? 16 * t.mt : 32 * t.mt * t.wm; }
 
 // K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
 // matrix pipes, so time ~ max blocks per CU x work per block); per-block work ~ BM x BN (K is fixed);
 // tile efficiency falls with operand traffic per FLOP (1/BM + 1/BN); a grid of <= 1 block per CU
 // cannot overlap its own loads with another block's MFMAs.
 static Tile pick_tile(int M, long npos, int nclass) {
-  static const Tile cand[] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {1, 2}, {2, 2}, {1, 4}};
+  if (CSTP_M16 && M > 128 && M <= 144 && npos * nclass >= 1024) return Tile{9, 1, 1};   // exact 144-row tile
+  static const Tile cand[] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}};
   Tile best = cand[0];
   double bestc = 1e300;
   for (const Tile& t : cand) {
@@ -620,12 +673,12 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   p.f_straddle = (d.c < 8);
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
-  p.f_Mp = cdiv(d.k, 32 * p.f_t.mt * p.f_t.wm) * 32 * p.f_t.mt * p.f_t.wm;
+  p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
   // dgrad: M = c, gather channels = k
   p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
-  p.d_Mp = cdiv(d.c, 32 * p.d_t.mt * p.d_t.wm) * 32 * p.d_t.mt * p.d_t.wm;
+  p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
   // wgrad: M = k, J = (tap, c)
   p.w_mt = pick_mt(d.k);
   p.w_straddle = (d.c < 8);
@@ -646,9 +699,13 @@ template <bool DGRAD, bool STRADDLE, bool XFORM>
 static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
                       const float* bias, float* out, int ntx, int ntm, const float2* in_ss, int in_npg, int in_relu) {
 #define CSTP_K1(MT_, WM_)                                                                                      \
-  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE, XFORM>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, \
+  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE, XFORM, false>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, \
                      ntm, in_ss, in_npg, in_relu)
-  if (tl.wm == 1) {
+  if (tl.m16) {
+    if (!STRADDLE)
+      hipLaunchKernelGGL((igemm_k1<9, 1, DGRAD, false, XFORM, true>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm,
+                         in_ss, in_npg, in_relu);
+  } else if (tl.wm == 1) {
     switch (tl.mt) {
       case 1: CSTP_K1(1, 1); break;
       case 2: CSTP_K1(2, 1); break;
@@ -729,7 +786,7 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.f_Cp; g.M = d.k; g.Mp = p.f_Mp; g.Ktot = p.ntaps * p.f_Cp;
   const int npos = d.n * p.Do * p.Ho * p.Wo;
-  const int f_bm = 32 * p.f_t.mt * p.f_t.wm, f_bn = 32 * (4 / p.f_t.wm);
+  const int f_bm = tile_bm(p.f_t), f_bn = 32 * (4 / p.f_t.wm);
   const int ntx = cdiv(npos, f_bn), ntm = cdiv(d.k, f_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
   InAffine ia;
@@ -762,7 +819,7 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   g.Cp = p.d_Cp; g.M = d.c; g.Mp = p.d_Mp; g.Ktot = p.ntaps * p.d_Cp;
   const int nclass = d.st * d.sh * d.sw;
   const int npos_max = d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw);
-  const int d_bm = 32 * p.d_t.mt * p.d_t.wm, d_bn = 32 * (4 / p.d_t.wm);
+  const int d_bm = tile_bm(p.d_t), d_bn = 32 * (4 / p.d_t.wm);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
   launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);

@@ -30,6 +30,8 @@ CONVS = [
     (1, 1152, 2, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),    # T7
     (2, 256, 2, 7, 7, 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # S6
     (1, 6, 1, 1, 1, 9, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # degenerate single position
+    (2, 144, 4, 14, 14, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),    # T1: data gradient on the 144-row 16x16x4 tile
+    (3, 40, 2, 9, 9, 136, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # 129..144 rows, ragged positions (16x16x4 tile tails)
 ]
 
 
