@@ -381,7 +381,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // K2: weight gradient.  dwp[m][j] += sum_{n in split} dy[m][n] * xcol[j][n],  j = tap*Cp + c
 // ------------------------------------------------------------------------------------------
-template <int MT, bool STRADDLE, bool VEC4, int BKN, bool XFORM>
+template <int MT, bool STRADDLE, bool VEC4, int BKN, bool XFORM, bool M16>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
          int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit,
@@ -390,11 +390,13 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
   // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
   // while the current one is multiplied (LDS double buffered, one barrier per tile).
-  constexpr int BM = 32 * MT, BJ = 128, LD = BKN + 1;
+  // M16: rows in MT tiles of 16 on the 16x16x4 MFMA (exact 144-row tile); its operand reads want an even
+  // row stride (2 k-columns per 32 lanes), the 32x32x2 reads an odd one
+  constexpr int BM = M16 ? 16 * MT : 32 * MT, BJ = 128, LD = M16 ? BKN + 2 : BKN + 1;
   constexpr int ARS = 256 / BKN;             // scalar A loader: dy-row step between a thread's loads
   constexpr int A4S = 1024 / BKN;            // float4 A loader: dy-row step
   constexpr int BSUB = 64 / BKN;             // B loader: xcol rows covered by one wave instruction
-  constexpr int AR = VEC4 ? BM / A4S : BM / ARS;   // dy loads per thread (float4 of 4 positions, or single floats)
+  constexpr int AR = VEC4 ? (BM + A4S - 1) / A4S : (BM + ARS - 1) / ARS;   // dy loads per thread (float4 / single floats)
   constexpr int BR = 32 / BSUB;              // xcol rows per thread (the wave gathers exactly the 32 columns it consumes)
   __shared__ float As[2][BM * LD];
   __shared__ float Bs[2][BJ * LD];
@@ -431,11 +433,16 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     wdh = rr / g.kw; wdw = rr - wdh * g.kw;
   }
 
-  f32x16 acc[MT];
+  f32x16 acc[M16 ? 1 : MT];
+  f32x4 acc16[M16 ? MT : 1][2];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < (M16 ? 1 : MT); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? MT : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc16[i][0][r] = 0.f; acc16[i][1][r] = 0.f; }
 
   const int lrow = lane >> 5, lcol = lane & 31;
   if (XFORM) {
@@ -528,14 +535,16 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
       for (int r = 0; r < AR; ++r) {
         const int ml = arow4 + A4S * r;
         const bool ok = a_valid4 && (m0 + ml) < g.M;
+        if (ml < BM) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) As[buf][ml * LD + 4 * q4 + i] = ok ? va[4 * r + i] : 0.f;
+          for (int i = 0; i < 4; ++i) As[buf][ml * LD + 4 * q4 + i] = ok ? va[4 * r + i] : 0.f;
+        }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
         const int ml = arow + ARS * r;
-        As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
+        if (ml < BM) As[buf][ml * LD + pos] = (a_valid && (m0 + ml) < g.M) ? va[r] : 0.f;
       }
     }
     if (wave_active) {
@@ -559,7 +568,20 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
   for (int kti = kt_begin; kti < kt_end; ++kti) {
     const bool have_next = (kti + 1) < kt_end;
     if (have_next) load_tile(kti + 1);
-    if (wave_active) {
+    if (wave_active && M16) {
+      const float* Ab = &As[buf][(lane & 15) * LD + (lane >> 4)];
+      const float* Bb = &Bs[buf][(wave * 32 + (lane & 15)) * LD + (lane >> 4)];
+#pragma unroll
+      for (int kk = 0; kk < BKN; kk += 4) {
+        const float b0 = Bb[kk], b1 = Bb[16 * LD + kk];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = Ab[mt * 16 * LD + kk];
+          acc16[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc16[mt][0], 0, 0, 0);
+          acc16[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc16[mt][1], 0, 0, 0);
+        }
+      }
+    } else if (wave_active) {
       const float* Ab = &As[buf][lcol * LD + lrow];
       const float* Bb = &Bs[buf][(wave * 32 + lcol) * LD + lrow];
       float a_cur[MT], a_nxt[MT], b_cur, b_nxt = 0.f;
@@ -573,20 +595,8 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = Ab[mt * 32 * LD + kk + 2];
         }
-#if CSTP_PIN_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this k-pair's MFMAs
-#endif
-#if CSTP_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
-#if CSTP_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if CSTP_PIN_PREFETCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int mt = 0; mt < (M16 ? 1 : MT); ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur, acc[mt], 0, 0, 0);
         b_cur = b_nxt;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
@@ -597,6 +607,24 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
     buf ^= 1;
   }
 
+  if (M16) {
+    if (wave_active) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int j = jw0 + nt * 16 + (lane & 15);
+        if (j >= Jtot) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + mt * 16 + (lane >> 4) * 4 + r;
+            if (m < g.M) atomicAdd(&dwp[(size_t)m * Jp + j], acc16[mt][nt][r]);
+          }
+        }
+      }
+    }
+    return;
+  }
   const int j = jw0 + lcol;
   if (wave_active && j < Jtot) {
 #pragma unroll
@@ -680,8 +708,8 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
   // wgrad: M = k, J = (tap, c)
-  p.w_mt = pick_mt(d.k);
   p.w_straddle = (d.c < 8);
+  p.w_mt = (CSTP_M16 && !p.w_straddle && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);   // 9 = nine 16-row tiles
   p.w_Cp = p.w_straddle ? d.c : (int)align_up(d.c, 32);
   p.w_Jtot = p.ntaps * p.w_Cp;
   p.w_Jp = (int)align_up(p.w_Jtot, 32);
@@ -726,8 +754,14 @@ static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const flo
                       int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit, const float2* in_ss,
                       int in_npg, int in_groups, int in_relu) {
 #define CSTP_K2(MT_)                                                                                              \
-  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN, XFORM>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, \
+  hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN, XFORM, false>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, \
                      kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu)
+  if (mt == 9) {   // 144-row tile on the 16x16x4 MFMA
+    if (!STRADDLE)
+      hipLaunchKernelGGL((igemm_k2<9, false, VEC4, BKN, XFORM, true>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp,
+                         kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu);
+    return;
+  }
   switch (mt) {
     case 1: CSTP_K2(1); break;
     case 2: CSTP_K2(2); break;
@@ -849,7 +883,7 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   const int npos = d.n * p.Do * p.Ho * p.Wo;
   const int bkn = CSTP_K2_BKN;
   const int kt_total = cdiv(npos, bkn);
-  const int ntm = cdiv(d.k, 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
+  const int ntm = cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
   int splits = cdiv(1024, ntm * ntj);
   if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
   if (splits < 1) splits = 1;
