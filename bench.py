@@ -178,7 +178,7 @@ def main():
                          "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH) else None,
                          "algorithmic_bytes_per_launch": 4.0 * (2 * args.batch * T * (HW // 2) * (HW // 2)) * (64 + 144)
                          + 4.0 * 144 * 64 * 9,
-                         "kernel": "igemm_k1<5,fwd> spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
+                         "kernel": "igemm_k1<9,1,fwd,M16> spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
                          "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
                          "algorithmic_gflop_per_launch": flops / 1e9},
         }
