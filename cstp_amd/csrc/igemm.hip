@@ -21,6 +21,14 @@
 #ifndef CSTP_SETPRIO
 #define CSTP_SETPRIO 0
 #endif
+#ifndef CSTP_NT_STORE
+#define CSTP_NT_STORE 1
+#endif
+#if CSTP_NT_STORE
+#define CSTP_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define CSTP_STORE(ptr, val) (*(ptr) = (val))
+#endif
 #ifndef CSTP_M16
 #define CSTP_M16 1          // 144-row tiles on the 16x16x4 MFMA for 129..144-channel layers
 #endif
@@ -310,17 +318,21 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   }
 
   if (M16) {
-    // C layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
-      if (n >= npos) continue;
-      size_t obase, cstride;
+    // C layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg, two column tiles per wave.  Lane groups
+    // q and q^1 swap one register (lane ^ 16) so that 32 consecutive lanes hold 32 consecutive columns of ONE row:
+    // every store instruction then writes whole 128-byte lines (the un-swapped layout writes 64-byte halves and
+    // the PMC WRITE_SIZE showed 1.37x the output bytes).
+    const int n = n0 + wn * 32 + lcol;                 // this lane's column after the swap
+    const int q = lane >> 4;
+    const bool odd = (q & 1) != 0;
+    size_t obase = 0, cstride = 0;
+    const bool nok = n < npos;
+    if (nok) {
       if (DGRAD) {
-        int q = n;
-        const int pw = q % Wp; q /= Wp;
-        const int ph = q % Hp; q /= Hp;
-        const int pd = q % Dp; const int b = q / Dp;
+        int qq = n;
+        const int pw = qq % Wp; qq /= Wp;
+        const int ph = qq % Hp; qq /= Hp;
+        const int pd = qq % Dp; const int b = qq / Dp;
         const int HWf = g.Hp * g.Wp;
         cstride = (size_t)g.Dp * HWf;
         obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
@@ -330,17 +342,19 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         cstride = (size_t)S;
         obase = (size_t)b * g.M * cstride + sp;
       }
+    }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + mt * 16 + (lane >> 4) * 4 + r;
-          if (m < g.M) {
-            float v = acc16[mt][nt][r];
-            if (bias != nullptr) v += bias[m];
-            out[obase + (size_t)m * cstride] = v;
-          }
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = acc16[mt][0][r], v1 = acc16[mt][1][r];
+        const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
+        const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
+        float ve = odd ? recv : v0;                    // row m_even: own cols 0-15 | partner's cols 16-31
+        float vo = odd ? v1 : recv;                    // row m_odd
+        // streaming (nt) stores: the output is not re-read by this kernel, keep the L2 for the input halo rows
+        if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
+        if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
       }
     }
     return;
@@ -371,7 +385,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         if (m < g.M) {
           float v = acc[mt][r];
           if (bias != nullptr) v += bias[m];
-          out[obase + (size_t)m * cstride] = v;
+          CSTP_STORE(out + obase + (size_t)m * cstride, v);
         }
       }
     }
