@@ -309,8 +309,8 @@ extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32
 
 extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var, float* save_mean,
-                                     float* save_invstd, int32_t n, int32_t c, int32_t s, int32_t groups, float eps,
-                                     float momentum, int32_t relu, void* ws, size_t ws_bytes) {
+                                     float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
+                                     int32_t groups, float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes) {
   CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "null argument");
   CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
   CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
@@ -332,7 +332,8 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
-                     running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta, nullptr);
+                     running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
+                     reinterpret_cast<float2*>(scale_shift));
   CSTP_LAUNCH_CHECK();
   const size_t total = (size_t)n * c * s;
   if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);

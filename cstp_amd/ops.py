@@ -158,11 +158,18 @@ class _BNAct(torch.autograd.Function):
         invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, groups)
         ws = _workspace(x.device, nbytes)
+        # ReLU without a residual: backward recomputes the mask from x with the affine table instead of re-reading y
+        remask = relu and res is None and s > 1
+        ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device) if remask else None
         check(lib.cstp_bn_forward_train(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                        _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), n, c, s,
-                                        groups, eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
+                                        _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), _ptr(ss),
+                                        n, c, s, groups, eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
               "cstp_bn_forward_train")
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        if remask:
+            ctx.save_for_backward(x, ss, gamma, mean, invstd)
+        else:
+            ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.remask = remask
         ctx.relu = relu
         ctx.groups = groups
         ctx.has_res = res is not None
@@ -171,7 +178,8 @@ class _BNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y_or_ss, gamma, mean, invstd = ctx.saved_tensors
+        y, ss = (None, y_or_ss) if ctx.remask else (y_or_ss, None)
         dy = _req(dy, "batch_norm grad_output")
         n, c = x.shape[0], x.shape[1]
         s = x.numel() // (n * c)
@@ -181,8 +189,8 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty_like(gamma)
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)
         ws = _workspace(x.device, nbytes)
-        check(lib.cstp_bn_backward(_stream(), x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                   invstd.data_ptr(), None, dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
+        check(lib.cstp_bn_backward(_stream(), x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                   invstd.data_ptr(), _ptr(ss), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
                                    c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 

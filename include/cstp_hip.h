@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 3
+#define CSTP_ABI_VERSION 4
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -76,12 +76,14 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
  *      e.g. the two views of a clip pair, r21d_byol.py:359-360): statistics are per (group, channel),
  *      running stats are updated group after group as successive F.batch_norm(training=True) calls would.
  *      save_mean/save_invstd: [groups][c] outputs for backward.  running_mean/var updated in place with
- *      `momentum` (unbiased variance). */
+ *      `momentum` (unbiased variance).  scale_shift (optional, s > 1): float[groups][c][2] affine form of the
+ *      normalisation; handing it to cstp_bn_backward lets the ReLU mask be recomputed from x instead of
+ *      re-reading y (two fewer HBM passes in the backward). */
 size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups);
 int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, float* save_mean,
-                          float* save_invstd, int32_t n, int32_t c, int32_t s, int32_t groups, float eps,
-                          float momentum, int32_t relu, void* ws, size_t ws_bytes);
+                          float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
+                          float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes);
 /* Statistics only: save_mean/save_invstd [groups][c], running stats update, and the affine table
  * scale_shift float[groups][c][2] = (invstd*gamma, beta - mean*invstd*gamma) that a consumer convolution
  * applies in its gather (cstp_in_affine) -- the BN output itself is never materialised. */
