@@ -102,14 +102,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # under torch.distributed.run
     if args.gpus != world:
         if args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
-        world, rank, local_rank = 1, 0, 0
+        world, rank, local_rank, launched = 1, 0, 0, False
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under the launcher the data-parallel machinery (RCCL process group, DDP gradient all-reduce, NT-Xent
+    # all-gather) runs even at world size 1, so the N = 1 launcher run exercises the N > 1 code path.
+    if launched:
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
 
     from cstp_amd import ops
@@ -125,7 +128,7 @@ def main():
     arenas = model.flatten_parameters()
     model.train()
     ddp = model
-    if world > 1:
+    if launched:
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         find_unused_parameters=False)
     opt = FlatSGD(model.parameters(), lr=0.09, momentum=0.9, weight_decay=5e-4, arenas=arenas)
@@ -143,18 +146,18 @@ def main():
             out.to_host()                        # the driver's per-iteration log read (one sync)
 
     run(args.warmup)
-    if world > 1:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if launched:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
@@ -185,7 +188,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

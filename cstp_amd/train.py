@@ -5,10 +5,12 @@
 deferred to ``StepOutput.to_host()``, called when the driver prints/logs)."""
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import torch
+import torch.distributed as dist
 
 from . import ops
 
@@ -39,16 +41,44 @@ def normalise_loss_weight(w):
     return w
 
 
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks of one flat tensor (the whole gradient arena): a single RCCL all-reduce over
+    xGMI instead of DDP's per-bucket copies (grad -> bucket -> grad costs ~4.7 ms/step at R18 on one MI355X,
+    more than the collective itself).  SUM then scale: gloo has no AVG."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+    return flat
+
+
 class PretrainStep:
+    """``flat_allreduce`` (default on when the model is DDP-wrapped and its gradients live in the flat arena):
+    DDP stays the launch surface and still broadcasts the BN buffers at each forward, but its per-bucket
+    gradient reducer is bypassed (``no_sync``) in favour of one all-reduce of the gradient arena after
+    backward.  Same result (mean of per-rank gradients), no bucket copies."""
+
     def __init__(self, model, optimizer, loss_weight, task="loss_com", clip_grad_norm=True, ntxent=None,
-                 ntxent_weight=0.0):
+                 ntxent_weight=0.0, flat_allreduce=True):
         self.model, self.optimizer, self.task = model, optimizer, task
         self.w = normalise_loss_weight(loss_weight)
         self.clip = bool(clip_grad_norm)
         self.ntxent, self.ntxent_weight = ntxent, float(ntxent_weight)
         self._inner = model.module if hasattr(model, "module") else model
+        arenas = getattr(self._inner, "_arenas", None)
+        self._flat_grad = arenas["grad"] if (flat_allreduce and arenas is not None and hasattr(model, "no_sync")) else None
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
+        sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
+        with sync_ctx:
+            out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
+        if self._flat_grad is not None:
+            allreduce_mean_(self._flat_grad)
+        gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None
+        self.optimizer.step()
+        out.grad_norm = gnorm
+        return out
+
+    def _forward_backward(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
         w = self.w
         loss_byol, logits = self.model(clip_1, clip_2, o_type=self.task)
         loss_byol = loss_byol.mean()
@@ -65,7 +95,5 @@ class PretrainStep:
             objective = loss_total + (self.ntxent_weight * self.ntxent.ddp_scale) * nt
         self.optimizer.zero_grad()
         objective.backward()
-        gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None
-        self.optimizer.step()
-        return StepOutput(loss_total.detach(), loss_byol.detach(), [c.detach() for c in ce], gnorm,
+        return StepOutput(loss_total.detach(), loss_byol.detach(), [c.detach() for c in ce], None,
                           None if nt is None else nt.detach(), [l.detach() for l in logits])

@@ -111,6 +111,15 @@ def _worker_grad_mean(rank, port, q):
     dist.destroy_process_group()
 
 
+def _worker_flat_allreduce(rank, port, q):
+    from cstp_amd.train import allreduce_mean_
+    _init(rank, port)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)       # rank r holds (r+1) * v
+    allreduce_mean_(g)
+    q.put((rank, float((g - torch.arange(1000, dtype=torch.float32) * 1.5).abs().max())))
+    dist.destroy_process_group()
+
+
 def _run(worker, nres):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -130,6 +139,11 @@ def test_ntxent_all_gather_gradient_and_ddp_scale():
         assert abs(loss - ref) < 1e-12          # every rank evaluates the same global loss
         assert err_full < 1e-12                 # DDP's mean over ranks of grad(world * loss) == global-batch gradient
         assert err_local < 1e-12
+
+
+def test_flat_gradient_allreduce_is_the_mean_over_ranks():
+    for rank, err in _run(_worker_flat_allreduce, WORLD):
+        assert err < 1e-6
 
 
 def test_clip_sharding_and_logging_allreduce():
