@@ -13,6 +13,11 @@
 // Block = 256 threads = 4 waves; block tile (32*MT) x 128; each wave owns a (32*MT) x 32 strip,
 // i.e. MT accumulators of 32x32 (16 VGPRs each).  Operands are staged global -> registers -> LDS
 // (coalesced along n, the NCDHW-contiguous axis) and double buffered in LDS.
+#include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 #ifndef CSTP_PIN_PREFETCH
@@ -674,6 +679,13 @@ static inline int tile_bm(const Tile& t) { return t.m16 ? 16 * t.mt : 32 * t.mt 
 // tile efficiency falls with operand traffic per FLOP (1/BM + 1/BN); a grid of <= 1 block per CU
 // cannot overlap its own loads with another block's MFMAs.
 static Tile pick_tile(int M, long npos, int nclass) {
+  // developer override for tile experiments: CSTP_TILE="mt,wm" (e.g. "4,1"); unset in production
+  static const char* ov = getenv("CSTP_TILE");
+  if (ov != nullptr) {
+    int mt = 0, wm = 0;
+    if (sscanf(ov, "%d,%d", &mt, &wm) == 2 && mt >= 1 && ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
+      return Tile{mt, wm, 0};
+  }
   if (CSTP_M16 && M > 128 && M <= 144 && npos * nclass >= 1024) return Tile{9, 1, 1};   // exact 144-row tile
   static const Tile cand[] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}};
   Tile best = cand[0];
@@ -689,6 +701,40 @@ static Tile pick_tile(int M, long npos, int nclass) {
     if (c < bestc * (1.0 - 1e-9)) { bestc = c; best = t; }
   }
   return best;
+}
+
+// ---- measured tile choices (cstp_conv3d_autotune) ------------------------------------------------
+// The analytic model above ranks tiles poorly on the deep layers (long K, few positions: L2 panel reuse and
+// grid fill interact), so the host may time the candidates once per (layer geometry, direction) and the
+// winner is remembered here.  All tiles run the same k-ordered fmaf chains: the choice never changes results.
+struct TuneKey {
+  int v[16];
+  bool operator==(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct TuneKeyHash {
+  size_t operator()(const TuneKey& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int i = 0; i < 16; ++i) h = (h ^ (size_t)(unsigned)k.v[i]) * 1099511628211ull;
+    return h;
+  }
+};
+static std::mutex g_tune_mu;
+static std::unordered_map<TuneKey, Tile, TuneKeyHash> g_tuned;
+static thread_local const Tile* g_force_tile = nullptr;   // set only inside cstp_conv3d_autotune
+
+static TuneKey tune_key(const cstp_conv_desc& d, int mode) {
+  TuneKey k;
+  const int f[16] = {d.n, d.c, d.d, d.h, d.w, d.k, d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw, mode};
+  memcpy(k.v, f, sizeof(f));
+  return k;
+}
+static bool lookup_tuned(const cstp_conv_desc& d, int mode, Tile& t) {
+  if (g_force_tile != nullptr) { t = *g_force_tile; return true; }
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  auto it = g_tuned.find(tune_key(d, mode));
+  if (it == g_tuned.end()) return false;
+  t = it->second;
+  return true;
 }
 
 struct ConvPlan {
@@ -711,13 +757,14 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   if (p.Do <= 0 || p.Ho <= 0 || p.Wo <= 0) return false;
   p.ntaps = d.kt * d.kh * d.kw;
   // forward: M = k, gather channels = c
-  p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
+  if (!lookup_tuned(d, 0, p.f_t)) p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
   p.f_straddle = (d.c < 8);
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
   p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
   // dgrad: M = c, gather channels = k
-  p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
+  if (!lookup_tuned(d, 1, p.d_t))
+    p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -731,7 +778,9 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
 }
 
 static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
-  size_t f = (size_t)p.f_Kp * p.f_Mp, g = (size_t)p.d_Kp * p.d_Mp, w = (size_t)d.k * p.w_Jp;
+  // packed-operand rows are padded to the tile height (<= 160): size for the tallest padding so that any tile
+  // (heuristic or tuned later) fits the workspace the caller sized once
+  size_t f = (size_t)p.f_Kp * ((size_t)d.k + 160), g = (size_t)p.d_Kp * ((size_t)d.c + 160), w = (size_t)d.k * p.w_Jp;
   size_t m = f > g ? f : g;
   if (w > m) m = w;
   return align_up(m * sizeof(float), 256);
@@ -923,5 +972,48 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp);
   CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src,
+                                    const float* w, float* out, void* ws, size_t ws_bytes, int32_t iters) {
+  CSTP_REQUIRE(desc && src && w && out && ws, "null argument");
+  CSTP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (backward_data)");
+  CSTP_REQUIRE(iters >= 1 && iters <= 100, "bad iteration count");
+  const cstp_conv_desc& d = *desc;
+  const int M = mode == 0 ? d.k : d.c;
+  const bool straddle = (mode == 0 && d.c < 8);
+  Tile cand[9] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}, {9, 1, 1}};
+  const int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
+  hipStream_t s = as_stream(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail("hipEventCreate failed%s", "");
+  float best_ms = 1e30f;
+  int best = -1, rc = 0;
+  for (int i = 0; i < ncand && rc == 0; ++i) {
+    if (cdiv(M, tile_bm(cand[i])) * tile_bm(cand[i]) > M + 160) continue;
+    g_force_tile = &cand[i];
+    for (int it = -1; it < iters && rc == 0; ++it) {      // it == -1: untimed warm-up launch
+      if (it == 0) (void)hipEventRecord(e0, s);
+      rc = mode == 0 ? cstp_conv3d_forward(stream, desc, src, w, nullptr, nullptr, out, ws, ws_bytes)
+                     : cstp_conv3d_backward_data(stream, desc, src, w, out, ws, ws_bytes);
+    }
+    g_force_tile = nullptr;
+    if (rc != 0) break;
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) { rc = fail("hipEventSynchronize failed%s", ""); break; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) { best_ms = ms; best = i; }
+  }
+  g_force_tile = nullptr;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != 0) return rc;
+  CSTP_REQUIRE(best >= 0, "no tile candidate ran");
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[tune_key(d, mode)] = cand[best];
+  }
   return 0;
 }

@@ -6,6 +6,7 @@ There is deliberately NO CPU implementation here: tensors must live on a HIP dev
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -57,6 +58,21 @@ def _triple(v) -> Tuple[int, int, int]:
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
 
+# Tile autotuning: the first time a convolution geometry is seen (per direction) the library times its tile
+# candidates once and remembers the winner (cstp_conv3d_autotune).  CSTP_AUTOTUNE=0 keeps the analytic choice.
+AUTOTUNE = os.environ.get("CSTP_AUTOTUNE", "1") != "0"
+_tuned = set()
+
+
+def _autotune(lib, desc, mode, src, w, out, ws):
+    key = (mode,) + tuple(getattr(desc, f) for f, _ in ConvDesc._fields_)
+    if key in _tuned:
+        return
+    _tuned.add(key)
+    check(lib.cstp_conv3d_autotune(_stream(), ctypes.byref(desc), mode, src.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), 2), "cstp_conv3d_autotune")
+
+
 def _desc(x_shape, w_shape, stride, padding) -> ConvDesc:
     n, c, d, h, w = x_shape
     k, c2, kt, kh, kw = w_shape
@@ -86,6 +102,8 @@ class _Conv3d(torch.autograd.Function):
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
         ws = _workspace(x.device, nbytes)
         b = None if bias is None else _req(bias, "conv3d bias")
+        if AUTOTUNE:
+            _autotune(lib, desc, 0, x, w, y, ws)
         tm = kernel_timer
         timed = tm is not None and tm.match("conv3d_forward", desc)
         if timed:
@@ -110,6 +128,8 @@ class _Conv3d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            if AUTOTUNE:
+                _autotune(lib, desc, 1, dy, w, dx, ws)
             check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
                                                 ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
         if ctx.needs_input_grad[1]:

@@ -15,7 +15,8 @@
  *     host or synchronises: calls only enqueue work (graph-capture safe).  Scratch comes from
  *     the caller through (ws, ws_bytes); query the size with the *_workspace_bytes functions.
  *   - return value: 0 on success, non-zero on error; cstp_last_error() returns a message for
- *     the calling thread.  No global mutable state besides that thread-local string.
+ *     the calling thread.  Global mutable state: that thread-local string and the (mutex-guarded) table of tuned
+ *     tile shapes written only by cstp_conv3d_autotune.
  */
 #ifndef CSTP_HIP_H
 #define CSTP_HIP_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 4
+#define CSTP_ABI_VERSION 5
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -68,6 +69,13 @@ int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const fl
 int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x,
                                 const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                 size_t ws_bytes);
+
+/* Optional one-off tuning, OUTSIDE graph capture: times the tile shapes of the forward (mode 0: src = x, out = y)
+ * or data-gradient (mode 1: src = dy, out = dx) kernel for this geometry on `stream` (this call DOES synchronise)
+ * and remembers the fastest in a process-wide table that later calls with the same descriptor consult.  Results
+ * are bit-identical for every tile shape; without tuning an analytic choice is used.  `out` is overwritten. */
+int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src, const float* w,
+                         float* out, void* ws, size_t ws_bytes, int32_t iters);
 
 /* ---- BatchNorm3d / BatchNorm1d in TRAIN mode, fused with the residual add and ReLU that follow
  *      it (r21d_byol.py:83-84,133-134,138-139,148,199-200,216; Projector/Predictor/heads BN1d).
