@@ -947,7 +947,9 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   const int bkn = CSTP_K2_BKN;
   const int kt_total = cdiv(npos, bkn);
   const int ntm = cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
-  int splits = cdiv(1024, ntm * ntj);
+  // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set (shorter tail, more dY streams in flight)
+  static const int k2_blocks = getenv("CSTP_K2_BLOCKS") ? atoi(getenv("CSTP_K2_BLOCKS")) : 2048;   // env: developer knob
+  int splits = cdiv(k2_blocks > 0 ? k2_blocks : 2048, ntm * ntj);
   if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
