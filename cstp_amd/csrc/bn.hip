@@ -139,84 +139,91 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
   dgamma[ch] = (float)t1;
 }
 
-// ---- stage 3 (forward): y = act((x-mean)*invstd*gamma + beta + residual) -----------------------
+// ---- stage 3: elementwise passes.  One block = one chunk of ONE (sample, channel) row, so the per-channel
+//      constants are block-uniform scalars and no per-element index division is needed (the flat-index form
+//      spent ~100 VALU instructions per float4 on 64-bit divisions and was VALU- rather than HBM-bound).
+constexpr int BN_UNROLL = 4;    // vectors per thread per block
+
+// forward: y = act((x-mean)*invstd*gamma + beta + residual)
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                    const float* __restrict__ invstd, size_t total, int c, int s, int npg, int relu) {
+                    const float* __restrict__ invstd, int c, int s, int npg, int relu, int chunks) {
   constexpr int W = VEC4 ? 4 : 1;
-  const size_t nvec = total / W;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-    const size_t e = i * W;
-    const size_t row = e / s;
-    const int ch = (int)(row % c);
-    const int gc = (int)(row / c) / npg * c + ch;
-    const float sc = invstd[gc] * gamma[ch];
-    const float sh = beta[ch] - mean[gc] * sc;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const float sc = invstd[gc] * gamma[ch];
+  const float sh = beta[ch] - mean[gc] * sc;
+  const size_t base = (size_t)row * s;
+#pragma unroll
+  for (int u = 0; u < BN_UNROLL; ++u) {
+    const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    if (e >= s) continue;
     if (VEC4) {
-      float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 v = *reinterpret_cast<const float4*>(x + base + e);
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
       if (res != nullptr) {
-        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        const float4 r = *reinterpret_cast<const float4*>(res + base + e);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      reinterpret_cast<float4*>(y)[i] = v;
+      *reinterpret_cast<float4*>(y + base + e) = v;
     } else {
-      float v = x[e] * sc + sh;
-      if (res != nullptr) v += res[e];
+      float v = x[base + e] * sc + sh;
+      if (res != nullptr) v += res[base + e];
       if (relu) v = fmaxf(v, 0.f);
-      y[e] = v;
+      y[base + e] = v;
     }
   }
 }
 
-// ---- stage 3 (backward): dx = gamma*invstd*(g - dbeta/cnt - xhat*dgamma/cnt); dres = g ---------
+// backward: dx = gamma*invstd*(g - dbeta/cnt - xhat*dgamma/cnt); dres = g
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                     const float* __restrict__ gsum, float* __restrict__ dx,
-                    float* __restrict__ dres, size_t total, int c, int s, int npg, float inv_count, int relu,
-                    const float2* __restrict__ ss) {
-  const bool remask = relu && (y == nullptr);
+                    float* __restrict__ dres, int c, int s, int npg, float inv_count, int relu,
+                    const float2* __restrict__ ss, int chunks) {
   constexpr int W = VEC4 ? 4 : 1;
-  const size_t nvec = total / W;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
-    const size_t e = i * W;
-    const size_t row = e / s;
-    const int ch = (int)(row % c);
-    const int gc = (int)(row / c) / npg * c + ch;
-    const float mu = mean[gc], is = invstd[gc];
-    const float k = gamma[ch] * is;
-    const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
-    float sc = 0.f, sh = 0.f;
-    if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
+  const bool remask = relu && (y == nullptr);
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const float mu = mean[gc], is = invstd[gc];
+  const float k = gamma[ch] * is;
+  const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
+  float sc = 0.f, sh = 0.f;
+  if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
+  const size_t base = (size_t)row * s;
+#pragma unroll
+  for (int u = 0; u < BN_UNROLL; ++u) {
+    const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    if (e >= s) continue;
     if (VEC4) {
-      const float4 v = reinterpret_cast<const float4*>(x)[i];
-      float4 g = reinterpret_cast<const float4*>(dy)[i];
+      const float4 v = *reinterpret_cast<const float4*>(x + base + e);
+      float4 g = *reinterpret_cast<const float4*>(dy + base + e);
       if (remask) {
         g.x = (v.x * sc + sh) > 0.f ? g.x : 0.f; g.y = (v.y * sc + sh) > 0.f ? g.y : 0.f;
         g.z = (v.z * sc + sh) > 0.f ? g.z : 0.f; g.w = (v.w * sc + sh) > 0.f ? g.w : 0.f;
       } else if (relu) {
-        const float4 o = reinterpret_cast<const float4*>(y)[i];
+        const float4 o = *reinterpret_cast<const float4*>(y + base + e);
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
-      if (dres != nullptr) reinterpret_cast<float4*>(dres)[i] = g;
+      if (dres != nullptr) *reinterpret_cast<float4*>(dres + base + e) = g;
       float4 o;
       o.x = k * (g.x - mb - (v.x - mu) * is * mg);
       o.y = k * (g.y - mb - (v.y - mu) * is * mg);
       o.z = k * (g.z - mb - (v.z - mu) * is * mg);
       o.w = k * (g.w - mb - (v.w - mu) * is * mg);
-      reinterpret_cast<float4*>(dx)[i] = o;
+      *reinterpret_cast<float4*>(dx + base + e) = o;
     } else {
-      float g = dy[e];
-      if (remask) { if (!((x[e] * sc + sh) > 0.f)) g = 0.f; }
-      else if (relu && !(y[e] > 0.f)) g = 0.f;
-      if (dres != nullptr) dres[e] = g;
-      dx[e] = k * (g - mb - (x[e] - mu) * is * mg);
+      float g = dy[base + e];
+      if (remask) { if (!((x[base + e] * sc + sh) > 0.f)) g = 0.f; }
+      else if (relu && !(y[base + e] > 0.f)) g = 0.f;
+      if (dres != nullptr) dres[base + e] = g;
+      dx[base + e] = k * (g - mb - (x[base + e] - mu) * is * mg);
     }
   }
 }
@@ -287,12 +294,6 @@ __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __rest
   dgamma[ch] = (float)t1;
 }
 
-static inline int ew_grid(size_t nvec) {
-  size_t b = (nvec + 255) / 256;
-  if (b > 8192) b = 8192;
-  if (b < 1) b = 1;
-  return (int)b;
-}
 
 }  // namespace cstp
 
@@ -335,9 +336,10 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
                      reinterpret_cast<float2*>(scale_shift));
   CSTP_LAUNCH_CHECK();
-  const size_t total = (size_t)n * c * s;
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, total, c, s, npg, relu);
+  const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -394,10 +396,11 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
   CSTP_LAUNCH_CHECK();
-  const size_t total = (size_t)n * c * s;
   const float inv_count = (float)(1.0 / ((double)npg * s));
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), dim3(ew_grid(total / 4)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu, ss2);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, total, c, s, npg, inv_count, relu, ss2);
+  const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
