@@ -721,6 +721,7 @@ struct TuneKeyHash {
 static std::mutex g_tune_mu;
 static std::unordered_map<TuneKey, Tile, TuneKeyHash> g_tuned;
 static thread_local const Tile* g_force_tile = nullptr;   // set only inside cstp_conv3d_autotune
+static thread_local int g_force_mode = -1;
 
 static TuneKey tune_key(const cstp_conv_desc& d, int mode) {
   TuneKey k;
@@ -729,7 +730,7 @@ static TuneKey tune_key(const cstp_conv_desc& d, int mode) {
   return k;
 }
 static bool lookup_tuned(const cstp_conv_desc& d, int mode, Tile& t) {
-  if (g_force_tile != nullptr) { t = *g_force_tile; return true; }
+  if (g_force_tile != nullptr && g_force_mode == mode) { t = *g_force_tile; return true; }
   std::lock_guard<std::mutex> lk(g_tune_mu);
   auto it = g_tuned.find(tune_key(d, mode));
   if (it == g_tuned.end()) return false;
@@ -744,7 +745,7 @@ struct ConvPlan {
   // dgrad
   Tile d_t; int d_Cp, d_Mp, d_Kp;
   // wgrad
-  int w_mt, w_Cp, w_Jtot, w_Jp; bool w_straddle;
+  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle;
 };
 
 static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
@@ -771,6 +772,11 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // wgrad: M = k, J = (tap, c)
   p.w_straddle = (d.c < 8);
   p.w_mt = (CSTP_M16 && !p.w_straddle && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);   // 9 = nine 16-row tiles
+  p.w_blocks = 2048;   // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set
+  {
+    Tile wt;
+    if (lookup_tuned(d, 2, wt)) { p.w_mt = wt.m16 ? 9 : wt.mt; p.w_blocks = 256 * wt.wm; }
+  }
   p.w_Cp = p.w_straddle ? d.c : (int)align_up(d.c, 32);
   p.w_Jtot = p.ntaps * p.w_Cp;
   p.w_Jp = (int)align_up(p.w_Jtot, 32);
@@ -947,9 +953,7 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   const int bkn = CSTP_K2_BKN;
   const int kt_total = cdiv(npos, bkn);
   const int ntm = cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
-  // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set (shorter tail, more dY streams in flight)
-  static const int k2_blocks = getenv("CSTP_K2_BLOCKS") ? atoi(getenv("CSTP_K2_BLOCKS")) : 2048;   // env: developer knob
-  int splits = cdiv(k2_blocks > 0 ? k2_blocks : 2048, ntm * ntj);
+  int splits = cdiv(p.w_blocks, ntm * ntj);
   if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
@@ -980,9 +984,50 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
 extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src,
                                     const float* w, float* out, void* ws, size_t ws_bytes, int32_t iters) {
   CSTP_REQUIRE(desc && src && w && out && ws, "null argument");
-  CSTP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (backward_data)");
+  CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
   CSTP_REQUIRE(iters >= 1 && iters <= 100, "bad iteration count");
   const cstp_conv_desc& d = *desc;
+  if (mode == 2) {
+    // weight gradient (src = x, w = dy, out = dw): row-tile height x split-K block target
+    const bool stem = d.c < 8;
+    Tile wc[16];
+    int nw = 0;
+    const int base = pick_mt(d.k);
+    for (int blocks = 4; blocks <= 16; blocks *= 2) {
+      wc[nw++] = Tile{base, blocks, 0};
+      if (!stem && d.k > 128 && d.k <= 144) wc[nw++] = Tile{9, blocks, 1};
+      for (int mt = 2; mt <= 5; ++mt)
+        if (mt != base && cdiv(d.k, 32 * mt) * 32 * mt <= cdiv(d.k, 32 * base) * 32 * base + 16 && nw < 15) wc[nw++] = Tile{mt, blocks, 0};
+    }
+    hipStream_t s2 = as_stream(stream);
+    hipEvent_t a0, a1;
+    if (hipEventCreate(&a0) != hipSuccess || hipEventCreate(&a1) != hipSuccess) return fail("hipEventCreate failed%s", "");
+    float bms = 1e30f;
+    int bi = -1, rc2 = 0;
+    for (int i = 0; i < nw && rc2 == 0; ++i) {
+      g_force_tile = &wc[i];
+      g_force_mode = 2;
+      for (int it = -1; it < iters && rc2 == 0; ++it) {
+        if (it == 0) (void)hipEventRecord(a0, s2);
+        rc2 = cstp_conv3d_backward_weight(stream, desc, src, nullptr, w, out, ws, ws_bytes);
+      }
+      g_force_tile = nullptr;
+      if (rc2 != 0) break;
+      (void)hipEventRecord(a1, s2);
+      if (hipEventSynchronize(a1) != hipSuccess) { rc2 = fail("hipEventSynchronize failed%s", ""); break; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, a0, a1);
+      if (ms < bms) { bms = ms; bi = i; }
+    }
+    g_force_tile = nullptr;
+    (void)hipEventDestroy(a0);
+    (void)hipEventDestroy(a1);
+    if (rc2 != 0) return rc2;
+    CSTP_REQUIRE(bi >= 0, "no weight-gradient candidate ran");
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[tune_key(d, 2)] = wc[bi];
+    return 0;
+  }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
   Tile cand[9] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}, {9, 1, 1}};
@@ -995,6 +1040,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   for (int i = 0; i < ncand && rc == 0; ++i) {
     if (cdiv(M, tile_bm(cand[i])) * tile_bm(cand[i]) > M + 160) continue;
     g_force_tile = &cand[i];
+    g_force_mode = mode;
     for (int it = -1; it < iters && rc == 0; ++it) {      // it == -1: untimed warm-up launch
       if (it == 0) (void)hipEventRecord(e0, s);
       rc = mode == 0 ? cstp_conv3d_forward(stream, desc, src, w, nullptr, nullptr, out, ws, ws_bytes)

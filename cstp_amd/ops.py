@@ -134,6 +134,8 @@ class _Conv3d(torch.autograd.Function):
                                                 ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
+            if AUTOTUNE:
+                _autotune(lib, desc, 2, x, dy, dw, ws)
             check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
                                                   dw.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_weight")
         if ctx.has_bias and ctx.needs_input_grad[2]:

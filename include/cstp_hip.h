@@ -70,8 +70,9 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
                                 const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                 size_t ws_bytes);
 
-/* Optional one-off tuning, OUTSIDE graph capture: times the tile shapes of the forward (mode 0: src = x, out = y)
- * or data-gradient (mode 1: src = dy, out = dx) kernel for this geometry on `stream` (this call DOES synchronise)
+/* Optional one-off tuning, OUTSIDE graph capture: times the tile shapes of the forward (mode 0: src = x, w = weights,
+ * out = y), data-gradient (mode 1: src = dy, w = weights, out = dx) or weight-gradient (mode 2: src = x, w = dy,
+ * out = dw; row-tile height x split-K block count) kernel for this geometry on `stream` (this call DOES synchronise)
  * and remembers the fastest in a process-wide table that later calls with the same descriptor consult.  Results
  * are bit-identical for every tile shape; without tuning an analytic choice is used.  `out` is overwritten. */
 int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src, const float* w,
