@@ -104,7 +104,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
 // to z (masked elements stay exactly 0).
 // M16: the rows are covered by MT tiles of 16 (v_mfma_f32_16x16x4_f32, same FLOP rate) instead of 32, so a
 // 144-channel layer (the S1/T1 class, 40 % of all FLOPs) runs an exact 144-row tile instead of padding to 160.
-template <int MT, int WM, bool DGRAD, bool STRADDLE, bool XFORM, bool M16>
+// TPB: K-tiles staged and multiplied per barrier (1 or 2).  Two tiles per barrier halve the block-wide
+// synchronisations and let twice as many gathers be in flight; the autotuner decides per geometry.
+template <int MT, int WM, bool DGRAD, bool STRADDLE, bool XFORM, bool M16, int TPB>
 __global__ void __launch_bounds__(256)
 igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ src, const float* __restrict__ bias,
          float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float2* __restrict__ in_ss, int in_npg,
@@ -116,8 +118,8 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
   constexpr int BRS = 256 / BN;          // row stride between them (2 / 4 / 8)
   static_assert(BM <= 160, "A staging holds at most 3 float4 per thread");
   static_assert(!M16 || WM == 1, "the 16-row variant uses the 128-column tile");
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BNP];
+  __shared__ __attribute__((aligned(16))) float As[2 * TPB][BK * BM];    // [buffer * TPB + slot]
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TPB][BK * BNP];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -177,9 +179,12 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
 
   constexpr int A_F4 = 4 * BM;                   // float4 per A tile (16 rows x BM/4)
   constexpr int A_ITERS = (A_F4 + 255) / 256;
-  float4 ra0, ra1, ra2;   // named registers (an indexed array here ends up in scratch)
-  ra0 = ra1 = ra2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float rb[BR];
+  struct Stage {              // one K-tile in flight: named float4 members (an indexed float4 array ends up in scratch)
+    float4 a0, a1, a2;
+    float b[BR];
+  };
+  Stage sg0, sg1;
+  sg0.a0 = sg0.a1 = sg0.a2 = sg1.a0 = sg1.a1 = sg1.a2 = make_float4(0.f, 0.f, 0.f, 0.f);
   static_assert(A_ITERS <= 3, "A tile staging assumes at most 3 float4 per thread");
 
   // iteration state
@@ -217,7 +222,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
     return tap < ntaps;
   };
 
-  auto load_tile = [&]() __attribute__((always_inline)) {
+  auto load_tile = [&](Stage& sg) __attribute__((always_inline)) {
     const int kbase = STRADDLE ? it * BK : tap * g.Cp + c0;
     {
       const float* abase = wp + (size_t)kbase * g.Mp + m0;
@@ -227,9 +232,9 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         const int row = idx / (BM / 4), c4 = idx - row * (BM / 4);
         return *reinterpret_cast<const float4*>(abase + (size_t)row * g.Mp + c4 * 4);
       };
-      ra0 = a_at(0);
-      if (A_ITERS > 1) ra1 = a_at(1);
-      if (A_ITERS > 2) ra2 = a_at(2);
+      sg.a0 = a_at(0);
+      if (A_ITERS > 1) sg.a1 = a_at(1);
+      if (A_ITERS > 2) sg.a2 = a_at(2);
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
@@ -257,29 +262,23 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         const float2 ss = in_ss[ss_b + (ok ? c0 + kr : 0)];
         float z = v * ss.x + ss.y;
         if (in_relu) z = fmaxf(z, 0.f);
-        rb[r] = ok ? z : 0.f;
+        sg.b[r] = ok ? z : 0.f;
       } else {
-        rb[r] = ok ? v : 0.f;
+        sg.b[r] = ok ? v : 0.f;
       }
     }
   };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    if (t < A_F4) *reinterpret_cast<float4*>(&As[buf][t * 4]) = ra0;
-    if (A_ITERS > 1 && t + 256 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 256) * 4]) = ra1;
-    if (A_ITERS > 2 && t + 512 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 512) * 4]) = ra2;
+  auto store_tile = [&](int buf, const Stage& sg) __attribute__((always_inline)) {   // buf = buffer * TPB + slot
+    if (t < A_F4) *reinterpret_cast<float4*>(&As[buf][t * 4]) = sg.a0;
+    if (A_ITERS > 1 && t + 256 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 256) * 4]) = sg.a1;
+    if (A_ITERS > 2 && t + 512 < A_F4) *reinterpret_cast<float4*>(&As[buf][(t + 512) * 4]) = sg.a2;
 #pragma unroll
-    for (int r = 0; r < BR; ++r) Bs[buf][(krow0 + BRS * r) * BNP + col] = rb[r];
+    for (int r = 0; r < BR; ++r) Bs[buf][(krow0 + BRS * r) * BNP + col] = sg.b[r];
   };
 
-  bool have = first_tile();
-  if (have) { load_tile(); store_tile(0); }
-  __syncthreads();
-  int buf = 0;
   const int lrow = lane >> 5, lcol = lane & 31;
   const int wm = wave % WM, wn = wave / WM;
-  while (have) {
-    const bool have_next = advance();
-    if (have_next) load_tile();
+  auto compute = [&](int buf) __attribute__((always_inline)) {     // buf = buffer * TPB + slot
     if (M16) {
       // 16x16x4: lane l feeds A[m = l&15][k = l>>4] and B[k = l>>4][n = l&15]; each wave owns 32 columns = 2 tiles
       const float* Ab = &As[buf][(lane >> 4) * BM + (lane & 15)];
@@ -316,10 +315,47 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
       }
     }
-    if (have_next) store_tile(buf ^ 1);
+  };
+
+  if (TPB == 1) {
+    bool have = first_tile();
+    if (have) { load_tile(sg0); store_tile(0, sg0); }
     __syncthreads();
-    buf ^= 1;
-    have = have_next;
+    int buf = 0;
+    while (have) {
+      const bool have_next = advance();
+      if (have_next) load_tile(sg0);
+      compute(buf);
+      if (have_next) store_tile(buf ^ 1, sg0);
+      __syncthreads();
+      buf ^= 1;
+      have = have_next;
+    }
+  } else {
+    bool h0 = first_tile(), h1 = false;
+    if (h0) {
+      load_tile(sg0);
+      h1 = advance();
+      if (h1) load_tile(sg1);
+      store_tile(0, sg0);
+      if (h1) store_tile(1, sg1);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (h0) {
+      const bool n0 = h1 && advance();     // a missing second tile means the sequence has ended
+      if (n0) load_tile(sg0);
+      const bool n1 = n0 && advance();
+      if (n1) load_tile(sg1);
+      compute(buf * 2);
+      if (h1) compute(buf * 2 + 1);
+      if (n0) store_tile((buf ^ 1) * 2, sg0);
+      if (n1) store_tile((buf ^ 1) * 2 + 1, sg1);
+      __syncthreads();
+      buf ^= 1;
+      h0 = n0;
+      h1 = n1;
+    }
   }
 
   if (M16) {
@@ -671,7 +707,7 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
   return best;
 }
 
-struct Tile { int mt, wm, m16; };
+struct Tile { int mt, wm, m16, tpb; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
 static inline int tile_bm(const Tile& t) { return t.m16 ? 16 * t.mt : 32 * t.mt * t.wm; }
 
 // K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
@@ -679,12 +715,13 @@ static inline int tile_bm(const Tile& t) { return t.m16 ? 16 * t.mt : 32 * t.mt 
 // tile efficiency falls with operand traffic per FLOP (1/BM + 1/BN); a grid of <= 1 block per CU
 // cannot overlap its own loads with another block's MFMAs.
 static Tile pick_tile(int M, long npos, int nclass) {
-  // developer override for tile experiments: CSTP_TILE="mt,wm" (e.g. "4,1"); unset in production
+  // developer override for tile experiments: CSTP_TILE="mt,wm[,tpb]" (e.g. "4,1" or "2,2,2"); unset in production
   static const char* ov = getenv("CSTP_TILE");
   if (ov != nullptr) {
-    int mt = 0, wm = 0;
-    if (sscanf(ov, "%d,%d", &mt, &wm) == 2 && mt >= 1 && ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
-      return Tile{mt, wm, 0};
+    int mt = 0, wm = 0, tpb = 1;
+    if (sscanf(ov, "%d,%d,%d", &mt, &wm, &tpb) >= 2 && mt >= 1 &&
+        ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
+      return Tile{mt, wm, 0, tpb == 2 ? 2 : 1};
   }
   if (CSTP_M16 && M > 128 && M <= 144 && npos * nclass >= 1024) return Tile{9, 1, 1};   // exact 144-row tile
   static const Tile cand[] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}};
@@ -792,16 +829,16 @@ static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   return align_up(m * sizeof(float), 256);
 }
 
-template <bool DGRAD, bool STRADDLE, bool XFORM>
-static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
-                      const float* bias, float* out, int ntx, int ntm, const float2* in_ss, int in_npg, int in_relu) {
+template <bool DGRAD, bool STRADDLE, bool XFORM, int TPB>
+static void launch_k1_t(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
+                        const float* bias, float* out, int ntx, int ntm, const float2* in_ss, int in_npg, int in_relu) {
 #define CSTP_K1(MT_, WM_)                                                                                      \
-  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE, XFORM, false>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, \
-                     ntm, in_ss, in_npg, in_relu)
+  hipLaunchKernelGGL((igemm_k1<MT_, WM_, DGRAD, STRADDLE, XFORM, false, TPB>), grid, dim3(256), 0, s, g, wp, src, bias, out, \
+                     ntx, ntm, in_ss, in_npg, in_relu)
   if (tl.m16) {
     if (!STRADDLE)
-      hipLaunchKernelGGL((igemm_k1<9, 1, DGRAD, false, XFORM, true>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx, ntm,
-                         in_ss, in_npg, in_relu);
+      hipLaunchKernelGGL((igemm_k1<9, 1, DGRAD, false, XFORM, true, TPB>), grid, dim3(256), 0, s, g, wp, src, bias, out, ntx,
+                         ntm, in_ss, in_npg, in_relu);
   } else if (tl.wm == 1) {
     switch (tl.mt) {
       case 1: CSTP_K1(1, 1); break;
@@ -816,6 +853,16 @@ static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const fl
     CSTP_K1(1, 4);
   }
 #undef CSTP_K1
+}
+
+template <bool DGRAD, bool STRADDLE, bool XFORM>
+static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const float* wp, const float* src,
+                      const float* bias, float* out, int ntx, int ntm, const float2* in_ss, int in_npg, int in_relu) {
+  // the two-tiles-per-barrier variant exists for the plain (non-stem, non-fused-BN) kernels only
+  if (tl.tpb == 2 && !STRADDLE && !XFORM)
+    launch_k1_t<DGRAD, false, false, 2>(tl, grid, s, g, wp, src, bias, out, ntx, ntm, in_ss, in_npg, in_relu);
+  else
+    launch_k1_t<DGRAD, STRADDLE, XFORM, 1>(tl, grid, s, g, wp, src, bias, out, ntx, ntm, in_ss, in_npg, in_relu);
 }
 
 template <bool STRADDLE, bool VEC4, int BKN, bool XFORM>
@@ -1030,8 +1077,13 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
-  Tile cand[9] = {{1, 1, 0}, {2, 1, 0}, {3, 1, 0}, {4, 1, 0}, {5, 1, 0}, {1, 2, 0}, {2, 2, 0}, {1, 4, 0}, {9, 1, 1}};
-  const int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
+  Tile cand[18] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
+                   {9, 1, 1, 1}};
+  int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
+  if (!straddle) {       // the same tiles with two K-tiles per barrier
+    const int n1 = ncand;
+    for (int i = 0; i < n1; ++i) { cand[ncand] = cand[i]; cand[ncand].tpb = 2; ++ncand; }
+  }
   hipStream_t s = as_stream(stream);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail("hipEventCreate failed%s", "");
