@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(ctypes.Structure):
@@ -48,11 +48,16 @@ SIGNATURES = {
                                       c_float, _P, c_size_t]),
     "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, _P, c_size_t]),
+    "cstp_bn_eval_workspace_bytes": (c_size_t, [c_int32]),
+    "cstp_bn_forward_eval": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, c_int32, _P,
+                                       c_size_t]),
     "cstp_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_channel_sum": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t]),
     "cstp_byol_loss_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32]),
     "cstp_byol_loss_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32]),
+    "cstp_l2_normalize_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float]),
+    "cstp_l2_normalize_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_float]),
     "cstp_cross_entropy_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32]),
     "cstp_cross_entropy_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32]),
     "cstp_ntxent_workspace_bytes": (c_size_t, [c_int32, c_int32]),
@@ -62,6 +67,7 @@ SIGNATURES = {
     "cstp_sumsq": (c_int32, [_P, _P, c_size_t, _P, _P, c_size_t]),
     "cstp_clip_coef": (c_int32, [_P, _P, c_float, _P, _P]),
     "cstp_sgd_step": (c_int32, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, _P, c_int32, c_int32]),
+    "cstp_adam_step": (c_int32, [_P, _P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_int32, c_int32]),
 }
 
 _lib = None

@@ -295,6 +295,29 @@ __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __rest
 }
 
 
+// ---- eval mode: the running statistics are the statistics (r21d_byol.py cls/val/test under model.eval()) ----
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ running_var, float* __restrict__ invstd, int c, float eps) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) invstd[ch] = 1.0f / sqrtf(running_var[ch] + eps);
+}
+
+__global__ void bn1d_eval_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ running_mean, const float* __restrict__ running_var, int n, int c,
+                                 float eps, int relu) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float sc = gamma[ch] / sqrtf(running_var[ch] + eps);
+  const float sh = beta[ch] - running_mean[ch] * sc;
+  for (int r = 0; r < n; ++r) {
+    float v = x[(size_t)r * c + ch] * sc + sh;
+    if (res != nullptr) v += res[(size_t)r * c + ch];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(size_t)r * c + ch] = v;
+  }
+}
+
+
 }  // namespace cstp
 
 using namespace cstp;
@@ -340,6 +363,34 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
   else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t cstp_bn_eval_workspace_bytes(int32_t c) { return c > 0 ? align_up((size_t)c * sizeof(float), 256) : 0; }
+
+extern "C" int cstp_bn_forward_eval(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                    const float* beta, const float* running_mean, const float* running_var, int32_t n,
+                                    int32_t c, int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(x && y && gamma && beta && running_mean && running_var, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  hipStream_t st = as_stream(stream);
+  if (s == 1) {
+    hipLaunchKernelGGL(bn1d_eval_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, residual, y, gamma, beta, running_mean,
+                       running_var, n, c, eps, relu);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_eval_workspace_bytes(c), "workspace too small");
+  float* invstd = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, running_var, invstd, c, eps);
+  CSTP_LAUNCH_CHECK();
+  const bool v4 = (s % 4) == 0;
+  const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  // one "group" spanning the whole batch: the apply kernel reads mean/invstd at [channel]
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

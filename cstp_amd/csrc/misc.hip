@@ -72,6 +72,35 @@ __global__ void byol_bwd_kernel(const float* __restrict__ x, const float* __rest
   for (int i = lane; i < f; i += 64) dx[(size_t)row * f + i] = g * (yp[i] / ny - cosv * xp[i] / nx);
 }
 
+// ---- F.normalize(x, p=2, dim=1) (r21d_byol.py:396): y = x / max(|x|, eps); one wave per row -------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ norm, int f,
+                                  float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* xp = x + (size_t)row * f;
+  float a = 0.f;
+  for (int i = lane; i < f; i += 64) a += xp[i] * xp[i];
+  a = wave_sum_all(a);
+  const float nrm = fmaxf(sqrtf(a), eps);
+  if (lane == 0) norm[row] = nrm;
+  const float inv = 1.0f / nrm;
+  for (int i = lane; i < f; i += 64) y[(size_t)row * f + i] = xp[i] * inv;
+}
+
+// dx = (dy - y <y, dy>) / max(|x|, eps)   (rows with |x| < eps: dx = dy / eps, as the clamp has zero slope)
+__global__ void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm, const float* __restrict__ dy,
+                                  float* __restrict__ dx, int f, float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* yp = y + (size_t)row * f;
+  const float* gp = dy + (size_t)row * f;
+  float d = 0.f;
+  for (int i = lane; i < f; i += 64) d += yp[i] * gp[i];
+  d = wave_sum_all(d);
+  const float nrm = norm[row];
+  if (!(nrm > eps)) d = 0.f;
+  const float inv = 1.0f / nrm;
+  for (int i = lane; i < f; i += 64) dx[(size_t)row * f + i] = (gp[i] - yp[i] * d) * inv;
+}
+
 // ---- CrossEntropyLoss(mean) ----------------------------------------------------------------------
 __global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ loss,
                               int b, int k) {
@@ -256,6 +285,24 @@ __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* 
   }
 }
 
+// torch.optim.Adam / AdamW (no amsgrad), bias corrections passed in as 1 - beta^t
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, const float* __restrict__ lr_p, float b1, float b2, float eps, float wd, int decoupled,
+                            float bc1, float bc2_sqrt) {
+  const float lr = lr_p[0];
+  const float step_size = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float pv = p[i], gr = g[i];
+    if (decoupled) pv *= (1.f - lr * wd);
+    else gr += wd * pv;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pv - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
 static inline int stream_grid(size_t n) {
   size_t b = (n + 255) / 256;
   if (b > 2048) b = 2048;
@@ -305,6 +352,22 @@ extern "C" int cstp_byol_loss_backward(void* stream, const float* x, const float
                                        int32_t b, int32_t f) {
   CSTP_REQUIRE(x && y && dloss && dx && b > 0 && f > 0, "bad argument");
   hipLaunchKernelGGL(byol_bwd_kernel, dim3(b), dim3(64), 0, as_stream(stream), x, y, dloss, dx, b, f);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_l2_normalize_forward(void* stream, const float* x, float* y, float* norm, int32_t rows, int32_t f,
+                                         float eps) {
+  CSTP_REQUIRE(x && y && norm && rows > 0 && f > 0, "bad argument");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows), dim3(64), 0, as_stream(stream), x, y, norm, f, eps);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_l2_normalize_backward(void* stream, const float* y, const float* norm, const float* dy, float* dx,
+                                          int32_t rows, int32_t f, float eps) {
+  CSTP_REQUIRE(y && norm && dy && dx && rows > 0 && f > 0, "bad argument");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows), dim3(64), 0, as_stream(stream), y, norm, dy, dx, f, eps);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -398,6 +461,17 @@ extern "C" int cstp_sgd_step(void* stream, float* p, float* g, float* buf, size_
   CSTP_REQUIRE(p && g && buf && lr && n > 0, "bad argument");
   hipLaunchKernelGGL(sgd_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
                      weight_decay, coef, first_step, write_back_grad);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_adam_step(void* stream, float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n,
+                              const float* lr, float beta1, float beta2, float eps, float weight_decay, int32_t decoupled,
+                              int32_t step) {
+  CSTP_REQUIRE(p && g && exp_avg && exp_avg_sq && lr && n > 0 && step > 0, "bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, decoupled, (float)bc1, (float)sqrt(bc2));
   CSTP_LAUNCH_CHECK();
   return 0;
 }

@@ -225,6 +225,29 @@ def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual
                         int(groups))
 
 
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=BN_EPS):
+    """y = act(batch_norm(x; running stats) + residual) -- model.eval().  Forward only: the reference evaluates under
+    torch.no_grad() (main_ft_mp.py:261, test.py:75), so asking for a gradient through it is an error, not a fallback."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad or beta.requires_grad
+                                    or (residual is not None and residual.requires_grad)):
+        raise _lib.CstpError("eval-mode BatchNorm is forward-only: call it under torch.no_grad() (as the reference's "
+                             "validation/test loops do)")
+    x = _req(x, "batch_norm input")
+    n, c = x.shape[0], x.shape[1]
+    s = x.numel() // (n * c)
+    res = None if residual is None else _req(residual, "residual")
+    if res is not None and res.shape != x.shape:
+        raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    ws = _workspace(x.device, lib.cstp_bn_eval_workspace_bytes(c))
+    check(lib.cstp_bn_forward_eval(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), _req(gamma, "weight").data_ptr(),
+                                   _req(beta, "bias").data_ptr(), _req(running_mean, "running_mean").data_ptr(),
+                                   _req(running_var, "running_var").data_ptr(), n, c, s, float(eps), 1 if relu else 0,
+                                   ws.data_ptr(), ws.numel()), "cstp_bn_forward_eval")
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # fused  BatchNorm(train) -> ReLU -> conv3d : the normalised tensor never exists in HBM
 # ----------------------------------------------------------------------------------------------
@@ -359,6 +382,38 @@ def byol_regression_loss(x, y):
     return _ByolLoss.apply(x, y.detach())
 
 
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        x = _req(x, "normalize input")
+        rows, f = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.cstp_l2_normalize_forward(_stream(), x.data_ptr(), y.data_ptr(), norm.data_ptr(), rows, f, eps),
+              "cstp_l2_normalize_forward")
+        ctx.save_for_backward(y, norm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, norm = ctx.saved_tensors
+        dy = _req(dy, "normalize grad_output")
+        dx = torch.empty_like(y)
+        check(lib.cstp_l2_normalize_backward(_stream(), y.data_ptr(), norm.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                             y.shape[0], y.shape[1], ctx.eps), "cstp_l2_normalize_backward")
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=1) for 2-D x (r21d_byol.py:396)."""
+    if x.dim() != 2:
+        raise _lib.CstpError("l2_normalize expects [rows, features], got %s" % (tuple(x.shape),))
+    return _L2Normalize.apply(x, float(eps))
+
+
 class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):
@@ -447,3 +502,11 @@ def sgd_step_(p, g, buf, lr: torch.Tensor, momentum: float, weight_decay: float,
     check(lib.cstp_sgd_step(_stream(), p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), lr.data_ptr(), float(momentum),
                             float(weight_decay), _ptr(coef), 1 if first_step else 0, 1 if write_back_grad else 0),
           "cstp_sgd_step")
+
+
+def adam_step_(p, g, exp_avg, exp_avg_sq, lr: torch.Tensor, beta1: float, beta2: float, eps: float, weight_decay: float,
+               decoupled: bool, step: int) -> None:
+    lib = _lib.load()
+    check(lib.cstp_adam_step(_stream(), p.data_ptr(), g.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), p.numel(),
+                             lr.data_ptr(), float(beta1), float(beta2), float(eps), float(weight_decay),
+                             1 if decoupled else 0, int(step)), "cstp_adam_step")

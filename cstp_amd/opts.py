@@ -45,7 +45,7 @@ _FLAGS = [
     ("dampening", 0.9, float, "accepted for compatibility; the reference never passes it to SGD"),
     ("weight_decay", 1e-4, float, "weight decay"),
     ("nesterov", False, None, "accepted for compatibility; unused by the reference driver"),
-    ("optimizer", "sgd", str, "sgd (flat-arena HIP kernel)"),
+    ("optimizer", "sgd", str, "sgd | adamw | adam (flat-arena HIP kernels)"),
     ("lr_patience", 10, int, "ReduceLROnPlateau patience (fine-tune only)"),
     ("n_epochs", 400, int, "epochs"),
     # logging / misc

@@ -2,8 +2,10 @@
 
 Mirrors (same class names, attribute names, state-dict keys, argument meaning and error
 behaviour) /root/reference/models/pace/r21d_byol.py:
-  SpatioTemporalConv :38-97, SpatioTemporalResBlock :100-148, SpatioTemporalResLayer :151-181,
-  R2Plus1DNet :184-229, Projector :232-243, Predictor :246-257, R21DBYOL :260-401.
+  get_fine_tuning_parameters :10-35, SpatioTemporalConv :38-97, SpatioTemporalResBlock :100-148,
+  SpatioTemporalResLayer :151-181, R2Plus1DNet :184-229, Projector :232-243, Predictor :246-257, R21DBYOL :260-401
+  (pretrain=True: o_type "loss_com"; pretrain=False: o_type "ft_fc" / "ft_all" / "test" -- online_net -> F.normalize ->
+  BatchNorm1d(512) -> Linear(512, num_classes), :293-299,394-399; BN uses running statistics under model.eval()).
 The module tree only holds parameters/buffers and sequences kernel launches; all arithmetic
 runs in the HIP kernels of libcstp_hip.so (cstp_amd.ops).  Differences from the reference,
 all additive:
@@ -40,6 +42,30 @@ def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
 
+def get_fine_tuning_parameters(model, ft_begin_index):
+    """r21d_byol.py:10-35.  ft_begin_index 0: every parameter.  Otherwise only parameters whose NAME contains one of
+    'layer<i>' (i = ft_begin_index..4) or 'classify' stay trainable -- and since this model's stages are called
+    conv1..conv5, that is the classifier alone for every non-zero index (kept as the reference behaves).  Every other
+    parameter is frozen (requires_grad False) and listed with lr 0.0, one param group per tensor."""
+    if ft_begin_index == 0:
+        return model.parameters()
+    ft_module_names = []
+    if ft_begin_index <= 4:
+        for i in range(ft_begin_index, 5):
+            ft_module_names.append("layer{}".format(i))
+    ft_module_names.append("classify")
+    print("Modules to finetune : ", ft_module_names)
+    parameters = []
+    for k, v in model.named_parameters():
+        if any(name in k for name in ft_module_names):
+            print("Layers to finetune : ", k)
+            parameters.append({"params": v})
+        else:
+            v.requires_grad = False
+            parameters.append({"params": v, "lr": 0.0})
+    return parameters
+
+
 # ---------------------------------------------------------------------------------------------
 # leaf modules: parameter holders with nn.Conv3d / nn.BatchNormNd / nn.Linear compatible
 # attribute names and default initialisers (so the CPU RNG stream is consumed identically)
@@ -61,7 +87,8 @@ class Conv3d(nn.Module):
 
 
 class _BatchNorm(nn.Module):
-    """Train-mode batch norm with optional fused residual add and ReLU."""
+    """Batch norm with optional fused residual add and ReLU (batch statistics in train mode, running statistics
+    in eval mode)."""
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1):
         super().__init__()
@@ -73,8 +100,11 @@ class _BatchNorm(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x, residual=None, relu=False, groups=1):
-        if not self.training:
-            raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
+        if not self.training:   # model.eval(): running statistics, nothing updated (validation / test)
+            return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
+        if x.numel() // x.shape[1] // groups <= 1:
+            # same failure the reference hits in nn.BatchNorm*d (train mode)
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
         y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps,
                                self.momentum, groups)
         if not getattr(self, "_nbt_in_arena", False):
@@ -85,7 +115,7 @@ class _BatchNorm(nn.Module):
         """conv(relu(self(x))) with this BN's apply+ReLU folded into ``conv``'s gather: only the statistics
         pass touches x before the convolution, and relu(bn(x)) is never written to HBM."""
         if not self.training:
-            raise NotImplementedError("cstp_amd implements the pre-training step (train-mode BN) only")
+            return conv(self(x, relu=True))
         y = ops.bn_relu_conv3d(x, self.weight, self.bias, self.running_mean, self.running_var, conv.weight, conv.stride,
                                conv.padding, groups, True, self.eps, self.momentum)
         if not getattr(self, "_nbt_in_arena", False):
@@ -129,7 +159,7 @@ class _MLP(nn.Sequential):
         super().__init__(Linear(dim, hidden), BatchNorm1d(hidden), ReLU(), Linear(hidden, out))
 
     def forward(self, x, groups=1):
-        if x.shape[0] // groups < 2:
+        if self.training and x.shape[0] // groups < 2:
             # same failure the reference hits in nn.BatchNorm1d (train mode)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
         h = self[0](x)
@@ -265,19 +295,26 @@ class R21DBYOL(nn.Module):
 
     def __init__(self, pretrain=True, momentum=0.996, layer_sizes=(1, 1, 1, 1), **kwargs):
         super().__init__()
-        if not pretrain:
-            raise NotImplementedError("cstp_amd implements the pre-training path (pretrain=True); fine-tune/test "
-                                      "(r21d_byol.py:293-299,394-399) is a later scope row")
-        self.momentum = momentum
+        self.pretrain = bool(pretrain)
         self.layer_sizes = tuple(layer_sizes)
-        self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
-        self.target_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
-        self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
-        self._set_grad(self.target_net, False)
-        self.overlap_spa = _MLP(1024, 1024, 5)
-        self.overlap_tem = _MLP(1024, 1024, 5)
-        self.pb_cls = _MLP(512, 512, 5)
-        self.rotate_cls = _MLP(512, 512, 5)
+        if pretrain:
+            self.momentum = momentum
+            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+            self.target_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+            self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
+            self._set_grad(self.target_net, False)
+            self.overlap_spa = _MLP(1024, 1024, 5)
+            self.overlap_tem = _MLP(1024, 1024, 5)
+            self.pb_cls = _MLP(512, 512, 5)
+            self.rotate_cls = _MLP(512, 512, 5)
+        else:
+            # fine-tune / test model (r21d_byol.py:293-299): encoder without projector + classifier
+            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=False)
+            self.classify = Linear(512, kwargs["num_classes"])
+            self.cls_bn = kwargs["cls_bn"]
+            if self.cls_bn:
+                print("classify_bn is true, Feature norm and Batch norm on final features")
+                self.cls_bn = BatchNorm1d(512)
         # Glorot-uniform overwrite of every Linear/Conv3d/BatchNorm weight, in modules() order
         # (r21d_byol.py:301-329) -- BN gamma becomes U(+-sqrt(6/C)), not 1.
         for m in self.modules():
@@ -305,8 +342,13 @@ class R21DBYOL(nn.Module):
 
     # -- flat HBM arenas --------------------------------------------------------------------------
     def trainable_parameters(self) -> List[nn.Parameter]:
-        """online_net, predictor, heads -- in parameters() order (the optimizer's order)."""
-        return [p for p in self.parameters() if p.requires_grad]
+        """The parameters an optimizer may update, in parameters() order: everything but the EMA target network
+        (pretrain: online_net, predictor, heads; fine-tune: online_net, classify, cls_bn -- frozen or not, so the
+        arena layout does not depend on the fine-tune task)."""
+        if not self.pretrain:
+            return list(self.parameters())
+        tgt = {id(p) for p in self.target_net.parameters()}
+        return [p for p in self.parameters() if id(p) not in tgt]
 
     @torch.no_grad()
     def flatten_parameters(self):
@@ -329,14 +371,14 @@ class R21DBYOL(nn.Module):
 
         train = self.trainable_parameters()
         online = list(self.online_net.parameters())
-        target = list(self.target_net.parameters())
-        assert [p.shape for p in online] == [p.shape for p in target]
+        target = list(self.target_net.parameters()) if self.pretrain else []
+        assert (not self.pretrain) or [p.shape for p in online] == [p.shape for p in target]
         assert all(a is b for a, b in zip(train[:len(online)], online)), "online_net must lead the trainable order"
         offs, n_train = layout(train)
         _, n_enc = layout(online)
         p_arena = torch.zeros(n_train, dtype=torch.float32, device=dev)
         g_arena = torch.zeros(n_train, dtype=torch.float32, device=dev)
-        t_arena = torch.zeros(n_enc, dtype=torch.float32, device=dev)
+        t_arena = torch.zeros(n_enc if self.pretrain else 0, dtype=torch.float32, device=dev)
         for p, o in zip(train, offs):
             v = p_arena[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
@@ -348,7 +390,11 @@ class R21DBYOL(nn.Module):
             p.data = v
         # one int64 arena per net for the BN counters: a single add_ per forward instead of 24+
         nbt = {}
-        for name, net in (("online", self.online_net), ("target", self.target_net), ("heads", None)):
+        if self.pretrain:
+            nets = (("online", self.online_net), ("target", self.target_net), ("heads", None))
+        else:
+            nets = (("all", self),)    # fine-tune: every BN (encoder + cls_bn) runs once per training forward
+        for name, net in nets:
             mods = []
             if net is not None:
                 mods = [m for m in net.modules() if isinstance(m, _BatchNorm)]
@@ -362,7 +408,8 @@ class R21DBYOL(nn.Module):
                 m._nbt_in_arena = True
             nbt[name] = arena
         # forward() calls per step: predictor x2, overlap_spa x1, overlap_tem x1, pb_cls x2, rotate_cls x2
-        nbt["heads_inc"] = torch.tensor([2, 1, 1, 2, 2], dtype=torch.long, device=dev)
+        if self.pretrain:
+            nbt["heads_inc"] = torch.tensor([2, 1, 1, 2, 2], dtype=torch.long, device=dev)
         self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
         return self._arenas
 
@@ -383,6 +430,9 @@ class R21DBYOL(nn.Module):
 
     def forward(self, x1, x2=None, o_type=None):
         if o_type == "loss_com":
+            if not self.pretrain:
+                raise AttributeError("R21DBYOL(pretrain=False) has no target_net/predictor: o_type='loss_com' needs "
+                                     "pretrain=True")
             if x2 is None or x2.shape != x1.shape:
                 raise ValueError("o_type='loss_com' needs two clips of identical shape")
             b = x1.shape[0]
@@ -420,6 +470,16 @@ class R21DBYOL(nn.Module):
             raise NotImplementedError("o_type='r_byol' is shape-broken in the reference (predictor fed a tuple, "
                                       "r21d_byol.py:384-385); use o_type='loss_com'")
         elif o_type in ["ft_fc", "ft_all", "test"]:
-            raise NotImplementedError("fine-tune / test outputs are outside the pre-training path")
+            if self.pretrain:
+                raise AttributeError("R21DBYOL(pretrain=True) has no classify/cls_bn: o_type=%r needs pretrain=False" % o_type)
+            online_feat = self.online_net(x1)                       # r21d_byol.py:395 (proj_flag False: features only)
+            online_feat = ops.l2_normalize(online_feat)             # F.normalize(p=2, dim=1) :396
+            if self.cls_bn is False or self.cls_bn is None:
+                raise TypeError("'bool' object is not callable")    # the reference calls self.cls_bn unconditionally (:397)
+            online_feat = self.cls_bn(online_feat)                  # :397
+            out = self.classify(online_feat)                        # :398
+            if self.training and self._arenas is not None:
+                self._arenas["nbt"]["all"] += 1
+            return out
         else:
             raise ValueError("Output cls is not exist!")

@@ -67,3 +67,57 @@ class CosineAnnealingWarmupRestarts:
 
     def load_state_dict(self, sd):
         self.__dict__.update(sd)
+
+
+class ReduceLROnPlateau:
+    """``optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'min', patience=opts.lr_patience)`` as the fine-tune driver
+    uses it (main_ft_mp.py:153, stepped with the epoch's validation loss at :279): factor 0.1, relative threshold 1e-4,
+    cooldown 0, min_lr 0, eps 1e-8 -- torch's defaults, restated as a plain state machine so it drives any optimizer
+    exposing ``param_groups`` (every group's lr is scaled, so the frozen groups at lr 0.0 stay at 0.0)."""
+
+    def __init__(self, optimizer, mode="min", factor=0.1, patience=10, threshold=1e-4, threshold_mode="rel", cooldown=0,
+                 min_lr=0.0, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        if mode not in ("min", "max"):
+            raise ValueError("mode " + mode + " is unknown!")
+        if threshold_mode not in ("rel", "abs"):
+            raise ValueError("threshold mode " + threshold_mode + " is unknown!")
+        self.optimizer, self.mode, self.factor, self.patience = optimizer, mode, factor, patience
+        self.threshold, self.threshold_mode, self.cooldown, self.eps = threshold, threshold_mode, cooldown, eps
+        self.min_lrs = [min_lr] * len(optimizer.param_groups)
+        self.best = math.inf if mode == "min" else -math.inf
+        self.num_bad_epochs = 0
+        self.cooldown_counter = 0
+        self.last_epoch = 0
+
+    def _is_better(self, a):
+        if self.mode == "min":
+            return a < (self.best * (1.0 - self.threshold) if self.threshold_mode == "rel" else self.best - self.threshold)
+        return a > (self.best * (1.0 + self.threshold) if self.threshold_mode == "rel" else self.best + self.threshold)
+
+    def step(self, metrics):
+        current = float(metrics)
+        self.last_epoch += 1
+        if self._is_better(current):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.num_bad_epochs = 0
+        if self.num_bad_epochs > self.patience:
+            for i, group in enumerate(self.optimizer.param_groups):
+                old_lr = float(group["lr"])
+                new_lr = max(old_lr * self.factor, self.min_lrs[i])
+                if old_lr - new_lr > self.eps:
+                    group["lr"] = new_lr
+            self.cooldown_counter = self.cooldown
+            self.num_bad_epochs = 0
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)

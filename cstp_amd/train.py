@@ -1,4 +1,4 @@
-"""One CSTP pre-training step on the GPU: the sequence of main_byol.py:60-91 --
+"""Training steps on the GPU.  ``FineTuneStep``: main_ft_mp.py:199-212.  ``PretrainStep``, one CSTP pre-training step: the sequence of main_byol.py:60-91 --
     model(clip_1, clip_2, o_type) -> 6x CrossEntropy -> loss_weight sum -> zero_grad ->
     backward (DDP all-reduces gradients on RCCL) -> clip_grad_norm_(18) -> SGD step
 -- with every scalar left on the device (the reference's seven .item() syncs per step are
@@ -97,3 +97,33 @@ class PretrainStep:
         objective.backward()
         return StepOutput(loss_total.detach(), loss_byol.detach(), [c.detach() for c in ce], None,
                           None if nt is None else nt.detach(), [l.detach() for l in logits])
+
+
+class FineTuneStep:
+    """One supervised step of main_ft_mp.py:199-212: ``outputs = model(inputs, o_type=task)`` ->
+    ``nn.CrossEntropyLoss()`` -> ``zero_grad`` -> ``backward`` -> ``optimizer.step()`` (no gradient clipping here).
+    Returns (loss, outputs) as DEVICE tensors; the caller derives accuracy from ``outputs`` as the reference does.
+    Under DDP the per-bucket reducer is bypassed (``no_sync``) and only the trainable runs of the flat gradient arena
+    are all-reduced -- for ft_fc that is the 52 K-float classifier instead of the 33 M-float encoder."""
+
+    def __init__(self, model, optimizer, task, flat_allreduce=True):
+        if task not in ("ft_fc", "ft_all"):
+            raise ValueError("o_type %r: the classifier forward serves 'ft_fc' / 'ft_all' (r21d_byol.py:394)" % (task,))
+        self.model, self.optimizer, self.task = model, optimizer, task
+        inner = model.module if hasattr(model, "module") else model
+        arenas = getattr(inner, "_arenas", None)
+        self._flat = flat_allreduce and arenas is not None and hasattr(model, "no_sync") and hasattr(optimizer, "_plan")
+        self._g = arenas["grad"] if arenas is not None else None
+
+    def __call__(self, inputs, targets):
+        sync_ctx = self.model.no_sync() if self._flat else contextlib.nullcontext()
+        with sync_ctx:
+            outputs = self.model(inputs, o_type=self.task)
+            loss = ops.cross_entropy(outputs, targets)
+            self.optimizer.zero_grad()
+            loss.backward()
+        if self._flat:
+            for off, n, _, _ in self.optimizer._plan():
+                allreduce_mean_(self._g[off:off + n])
+        self.optimizer.step()
+        return loss.detach(), outputs.detach()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 5
+#define CSTP_ABI_VERSION 6
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -107,6 +107,14 @@ int cstp_bn_backward(void* stream, const float* x, const float* y, const float* 
                      float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
                      int32_t relu, void* ws, size_t ws_bytes);
 
+/* EVAL mode (model.eval(): main_ft_mp.py:254-262 validation, test.py:74-76): the running statistics are the
+ * statistics -- y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta + residual); nothing is updated.
+ * Forward only (the reference evaluates under torch.no_grad()).  ws: cstp_bn_eval_workspace_bytes(c) when s > 1. */
+size_t cstp_bn_eval_workspace_bytes(int32_t c);
+int cstp_bn_forward_eval(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                         const float* beta, const float* running_mean, const float* running_var, int32_t n, int32_t c,
+                         int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes);
+
 /* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
 int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);
 int cstp_avgpool_backward(void* stream, const float* dy, float* dx, int32_t rows, int32_t s);
@@ -120,6 +128,11 @@ int cstp_channel_sum(void* stream, const float* x, float* out, int32_t n, int32_
 int cstp_byol_loss_forward(void* stream, const float* x, const float* y, float* loss, int32_t b, int32_t f);
 int cstp_byol_loss_backward(void* stream, const float* x, const float* y, const float* dloss, float* dx,
                             int32_t b, int32_t f);
+/* F.normalize(x, p=2, dim=1) of the fine-tune/test head (r21d_byol.py:396): y = x / max(|x|_2, eps), x,y [rows][f];
+ * norm[rows] = max(|x|, eps) is kept for the backward: dx = (dy - y <y, dy>) / norm. */
+int cstp_l2_normalize_forward(void* stream, const float* x, float* y, float* norm, int32_t rows, int32_t f, float eps);
+int cstp_l2_normalize_backward(void* stream, const float* y, const float* norm, const float* dy, float* dx, int32_t rows,
+                               int32_t f, float eps);
 /* nn.CrossEntropyLoss() (mean) main_byol.py:63-68: logits [b][k], labels int64 [b] -> loss[1].
  * backward: dlogits = dloss[0] * (softmax - onehot) / b. */
 int cstp_cross_entropy_forward(void* stream, const float* logits, const int64_t* labels, float* loss, int32_t b,
@@ -147,6 +160,11 @@ int cstp_clip_coef(void* stream, const float* sumsq, float max_norm, float* coef
  *   buf = first_step ? g' : momentum*buf + g';  p -= lr[0]*buf.   lr is a DEVICE scalar. */
 int cstp_sgd_step(void* stream, float* p, float* g, float* buf, size_t n, const float* lr, float momentum,
                   float weight_decay, const float* coef, int32_t first_step, int32_t write_back_grad);
+/* torch.optim.Adam (decoupled = 0: g += wd*p) / AdamW (decoupled = 1: p *= 1 - lr*wd), no amsgrad
+ * (main_ft_mp.py:139-147): m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  `step` counts from 1; lr is a DEVICE scalar. */
+int cstp_adam_step(void* stream, float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, const float* lr,
+                   float beta1, float beta2, float eps, float weight_decay, int32_t decoupled, int32_t step);
 
 #ifdef __cplusplus
 }

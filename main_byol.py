@@ -32,7 +32,7 @@ from torch.utils.data.distributed import DistributedSampler
 
 from cstp_amd.model import generate_model
 from cstp_amd.ntxent import NTXentLoss
-from cstp_amd.optim import FlatSGD
+from cstp_amd.optim import build_optimizer
 from cstp_amd.opts import parse_opts
 from cstp_amd.scheduler import CosineAnnealingWarmupRestarts
 from cstp_amd.synthetic import SyntheticClips
@@ -127,10 +127,7 @@ def main_worker(local_rank, opts):
         opts.dataset, opts.sample_duration, opts.model_name, opts.model_depth)), LOG_COLUMNS, overlay=True) \
         if local_rank == 0 else None
 
-    if opts.optimizer != "sgd":
-        raise NotImplementedError("--optimizer %s: the HIP path implements sgd (the reference recipe)" % opts.optimizer)
-    optimizer = FlatSGD(parameters, lr=opts.learning_rate, momentum=opts.momentum, weight_decay=opts.weight_decay,
-                        arenas=inner.flatten_parameters())
+    optimizer = build_optimizer(opts, parameters, inner.flatten_parameters())   # sgd | adamw | adam (main_byol.py:227-244)
     scheduler = CosineAnnealingWarmupRestarts(optimizer, first_cycle_steps=opts.n_epochs, cycle_mult=1.0,
                                               max_lr=opts.learning_rate, min_lr=0.00001,
                                               warmup_steps=0.5 * opts.n_epochs, gamma=0.5)

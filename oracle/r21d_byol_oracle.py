@@ -87,7 +87,7 @@ def _mlp_spec(prefix: str, din: int, dhid: int, dout: int):
     return spec
 
 
-def encoder_spec(prefix: str, layer_sizes: Sequence[int]):
+def encoder_spec(prefix: str, layer_sizes: Sequence[int], proj: bool = True):
     spec = _stconv_spec(prefix + ".conv1", 3, 64, (3, 7, 7))
     spec += _bn_spec(prefix + ".bn1", 64)
     chans = [(64, 64, False), (64, 128, True), (128, 256, True), (256, 512, True)]
@@ -96,7 +96,8 @@ def encoder_spec(prefix: str, layer_sizes: Sequence[int]):
         spec += _block_spec(lp + ".block1", cin, cout, ds)
         for bi in range(n - 1):
             spec += _block_spec("%s.blocks.%d" % (lp, bi), cout, cout, False)
-    spec += _mlp_spec(prefix + ".project.net", 512, 4096, 512)
+    if proj:     # proj_flag (r21d_byol.py:211-213)
+        spec += _mlp_spec(prefix + ".project.net", 512, 4096, 512)
     return spec
 
 
@@ -252,7 +253,7 @@ def mlp(sd, prefix: str, x, training=True):
     return F.linear(x, sd[prefix + ".3.weight"], sd[prefix + ".3.bias"])
 
 
-def encoder_forward(sd, prefix: str, x, layer_sizes, training=True):
+def encoder_forward(sd, prefix: str, x, layer_sizes, training=True, proj=True):
     x = st_conv(sd, prefix + ".conv1", x, (3, 7, 7), (1, 2, 2), (1, 3, 3), training)
     x = F.relu(_bn(sd, prefix + ".bn1", x, training))
     for li, n in enumerate(layer_sizes):
@@ -261,8 +262,9 @@ def encoder_forward(sd, prefix: str, x, layer_sizes, training=True):
         for bi in range(n - 1):
             x = res_block(sd, "%s.blocks.%d" % (lp, bi), x, False, training)
     feat = x.mean(dim=(2, 3, 4)).view(-1, 512)
-    proj = mlp(sd, prefix + ".project.net", feat, training)
-    return feat, proj
+    if not proj:     # proj_flag False: features only (r21d_byol.py:225-229)
+        return feat
+    return feat, mlp(sd, prefix + ".project.net", feat, training)
 
 
 def ema_update(sd, layer_sizes, m: float = EMA_MOMENTUM):

@@ -116,13 +116,13 @@ def test_model_interface_errors():
     from cstp_amd.r21d_byol import R21DBYOL, layer_sizes_for_depth
     with pytest.raises(ValueError):
         layer_sizes_for_depth(50)
-    with pytest.raises(NotImplementedError):
-        R21DBYOL(pretrain=False, num_classes=101, cls_bn=True)
+    with pytest.raises(KeyError):
+        R21DBYOL(pretrain=False)                 # the reference reads kwargs["num_classes"] (r21d_byol.py:295)
     o = parse_opts(["--model_name", "c3d_byol", "--task", "loss_com"])
     with pytest.raises(ValueError):
         generate_model(o)
-    o = parse_opts(["--model_name", "r21d_byol", "--task", "ft_all"])
-    with pytest.raises(NotImplementedError):
+    o = parse_opts(["--model_name", "r21d_byol", "--task", "r_ctr"])
+    with pytest.raises(ValueError):
         generate_model(o)
     if not torch.cuda.is_available():
         o = parse_opts(["--model_name", "r21d_byol", "--task", "loss_com", "--model_depth", "1"])
