@@ -102,7 +102,10 @@ class FlatSGD(_FlatOptimizer):
         params = list(params)
         if params and not isinstance(params[0], dict):
             params = [p for p in params if p.requires_grad]
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay), arenas)
+        # the remaining torch.optim.SGD group keys ride along (fixed at what this kernel implements) so that a
+        # state_dict written here loads into torch.optim.SGD -- i.e. into the reference -- and steps there
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False,
+                                      maximize=False, foreach=None, differentiable=False, fused=None), arenas)
         self._buf = torch.zeros_like(self._p)
         self._steps = 0
 
@@ -149,7 +152,9 @@ class FlatAdam(_FlatOptimizer):
         params = list(params)
         if params and not isinstance(params[0], dict):
             params = [p for p in params if p.requires_grad]
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay), arenas)
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=bool(decoupled)), arenas)
         self.decoupled = bool(decoupled)
         self._m = torch.zeros_like(self._p)
         self._v = torch.zeros_like(self._p)

@@ -124,18 +124,32 @@ def main_worker(local_rank, opts):
     print("Model is loaded successfully!")
     inner = model.module if hasattr(model, "module") else model
     train_logger = Logger(os.path.join(log_path, "{}_train_clip{}model{}{}.log".format(
-        opts.dataset, opts.sample_duration, opts.model_name, opts.model_depth)), LOG_COLUMNS, overlay=True) \
+        opts.dataset, opts.sample_duration, opts.model_name, opts.model_depth)), LOG_COLUMNS,
+        overlay=not opts.resume_md_path) \
         if local_rank == 0 else None
 
     optimizer = build_optimizer(opts, parameters, inner.flatten_parameters())   # sgd | adamw | adam (main_byol.py:227-244)
+    begin_epoch = 1
+    if opts.resume_md_path:
+        # The reference only reloads the optimizer for --task resume and then trains nothing (main_byol.py:246-247,
+        # 260).  Here --resume_md_path continues a loss_com run: weights (online, target, heads, BN buffers), momentum
+        # buffers, the epoch counter (checkpoints store epoch + 1) and the schedule position.
+        md = torch.load(opts.resume_md_path, map_location=torch.device("cuda", local_rank))
+        assert opts.arch == md["arch"]
+        model.load_state_dict(md["state_dict"])
+        optimizer.load_state_dict(md["optimizer"])
+        begin_epoch = int(md["epoch"])
+        print("Resume model {} at epoch {}".format(opts.resume_md_path, begin_epoch))
     scheduler = CosineAnnealingWarmupRestarts(optimizer, first_cycle_steps=opts.n_epochs, cycle_mult=1.0,
                                               max_lr=opts.learning_rate, min_lr=0.00001,
                                               warmup_steps=0.5 * opts.n_epochs, gamma=0.5)
+    for _ in range(1, begin_epoch):
+        scheduler.step()
     step_fn = PretrainStep(model, optimizer, opts.loss_weight, task=opts.task, clip_grad_norm=opts.clip_grad_norm,
                            ntxent=criterion_ctr, ntxent_weight=opts.ntxent_weight)
     if opts.task in ("r_byol", "loss_com"):
         print("Start to train BYOL CoCLR data augmentation pre-trained model!")
-        for epoch in range(1, opts.n_epochs + 1):
+        for epoch in range(begin_epoch, opts.n_epochs + 1):
             print("Training BYOL at epoch {}".format(epoch))
             if sampler is not None:
                 sampler.set_epoch(epoch)

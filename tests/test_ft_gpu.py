@@ -242,6 +242,21 @@ def test_drivers_pretrain_checkpoint_to_finetune_to_test(tmp_path, capsys):
     assert pre_sd["arch"] == "r21d_byol-1" and pre_sd["epoch"] == 101      # epoch + 1, main_byol.py:134
     pre_sd = pre_sd["state_dict"]
     assert "module.target_net.bn1.running_mean" in pre_sd and "module.predictor.net.0.weight" in pre_sd
+    # --resume_md_path continues the run: epochs 101-102 are appended, at the schedule's lr for those epochs
+    res_opts = parse_opts(common + ["--task", "loss_com", "--loss_weight", "0.1", "1", "1", "1", "1", "--n_epochs", "102",
+                                    "--max_steps", "1", "--learning_rate", "0.01", "--resume_md_path", ckpt])
+    _load_script("main_byol").main(res_opts)
+    rows = open(str(tmp_path / "synthetic" / "loss_com" / "synthetic_train_clip4modelr21d_byol1.log")).read().strip().split("\n")
+    assert [r.split("\t")[0] for r in rows[-3:]] == ["100", "101", "102"]
+    from cstp_amd.scheduler import CosineAnnealingWarmupRestarts
+
+    class _Opt:
+        param_groups = [{"lr": 0.0}]
+    sch = CosineAnnealingWarmupRestarts(_Opt(), first_cycle_steps=102, cycle_mult=1.0, max_lr=0.01, min_lr=0.00001,
+                                        warmup_steps=51.0, gamma=0.5)
+    for _ in range(101):
+        sch.step()
+    assert abs(float(rows[-1].split("\t")[-1]) - float("{:.5f}".format(_Opt.param_groups[0]["lr"]))) < 1e-9
     accs = {}
     for task, lr, epochs in (("ft_all", "0.02", "6"), ("ft_fc", "0.05", "2")):
         opts = parse_opts(common + ["--task", task, "--pretrained_path", ckpt, "--learning_rate", lr, "--n_epochs", epochs])

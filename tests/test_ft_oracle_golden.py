@@ -184,3 +184,83 @@ def test_labelled_synthetic_dataset_and_loader():
     assert len(loader) == 3                                # ... not on val
     out = torch.tensor([[0.1, 0.9], [0.8, 0.2], [0.3, 0.7], [0.6, 0.4]])
     assert math.isclose(calculate_accuracy(out, torch.tensor([1, 0, 0, 0])), 0.75)
+
+
+def _cpu_arena_params(sizes):
+    offs, n = [], 0
+    for s in sizes:
+        offs.append(n)
+        n += (int(np.prod(s)) + 3) // 4 * 4
+    arena = {"param": torch.arange(n, dtype=torch.float32) * 0.01, "grad": torch.zeros(n)}
+    params = []
+    for s, o in zip(sizes, offs):
+        p = torch.nn.Parameter(torch.empty(s))
+        p.data = arena["param"][o:o + int(np.prod(s))].view(s)
+        params.append(p)
+    return arena, params, offs
+
+
+def test_optimizer_state_dict_is_torch_wire_format():
+    """Checkpoints carry ``optimizer.state_dict()`` (main_byol.py:139, main_ft_mp.py:291): what the flat optimizers
+    write must load into torch.optim.SGD / Adam / AdamW (the reference's resume path, main_ft_mp.py:149-150) and step
+    there, and what torch writes must load back."""
+    from cstp_amd.optim import FlatAdam, FlatSGD
+    sizes = [(3, 5), (6,), (2, 2, 3)]
+    arena, params, offs = _cpu_arena_params(sizes)
+    opt = FlatSGD(params, lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=arena)
+    opt._buf.copy_(torch.arange(opt._buf.numel(), dtype=torch.float32) * 0.5)
+    opt._steps = 1
+    sd = opt.state_dict()
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    ref = torch.optim.SGD(clones, lr=1.0, momentum=0.0)
+    ref.load_state_dict(sd)
+    assert ref.param_groups[0]["lr"] == 0.05 and ref.param_groups[0]["momentum"] == 0.9
+    for (s, o), c in zip(zip(sizes, offs), clones):
+        n = int(np.prod(s))
+        assert torch.equal(ref.state[c]["momentum_buffer"], opt._buf[o:o + n].view(s))
+        c.grad = torch.ones_like(c)
+    ref.step()                                            # every key torch's step needs is present
+    back = FlatSGD(params, lr=0.1, momentum=0.0, arenas=arena)
+    back.load_state_dict(ref.state_dict())
+    assert back._steps == 1 and back.param_groups[0]["lr"] == 0.05 and back.param_groups[0]["weight_decay"] == 5e-4
+    for (s, o), c in zip(zip(sizes, offs), clones):
+        n = int(np.prod(s))
+        assert torch.equal(back._buf[o:o + n].view(s), ref.state[c]["momentum_buffer"])
+    for decoupled, cls in ((False, torch.optim.Adam), (True, torch.optim.AdamW)):
+        opt = FlatAdam(params, lr=0.01, betas=(0.9, 0.99), weight_decay=1e-2, decoupled=decoupled, arenas=arena)
+        opt._m.fill_(0.25)
+        opt._v.fill_(0.5)
+        opt._steps = 3
+        clones = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        ref = cls(clones, lr=1.0)
+        ref.load_state_dict(opt.state_dict())
+        assert ref.param_groups[0]["betas"] == (0.9, 0.99) and float(ref.state[clones[0]]["step"]) == 3
+        for c in clones:
+            c.grad = torch.ones_like(c)
+        ref.step()
+        back = FlatAdam(params, decoupled=decoupled, arenas=arena)
+        back.load_state_dict(ref.state_dict())
+        assert back._steps == 4 and back.param_groups[0]["lr"] == 0.01
+
+
+def test_get_dataloader_shards_across_ranks():
+    """utils.py:91-163 under DDP: GLOBAL batch split over ranks, disjoint shards, train drops the ragged tail."""
+    from cstp_amd.opts import parse_opts
+    from cstp_amd.synthetic import SyntheticLabelledClips
+    from cstp_amd.utils import get_dataloader
+    ds = SyntheticLabelledClips("train", length=22, sample_duration=2, sample_size=8, n_classes=3, seed=1)
+    seen = []
+    for rank in (0, 1):
+        o = parse_opts(["--batch_size", "8", "--n_workers", "0"])
+        o.distributed, o.world_size, o.rank = True, 2, rank
+        loader, sampler = get_dataloader(ds, o, "train")
+        sampler.set_epoch(3)
+        assert loader.batch_size == 4 and o.batch_size == 8 and len(loader) == 2     # 11 per rank -> 2 full batches
+        seen.append(set(iter(sampler)))
+        vloader, vsampler = get_dataloader(ds, o, "val")
+        assert len(vloader) == 3 and list(iter(vsampler)) == list(range(rank, 22, 2))
+        o2 = parse_opts(["--batch_size", "8", "--n_workers", "0"])
+        o2.distributed, o2.world_size, o2.rank = True, 2, rank
+        get_dataloader(ds, o2, "byol")
+        assert o2.batch_size == 4                                                    # utils.py:98 overwrites it
+    assert seen[0].isdisjoint(seen[1]) and len(seen[0] | seen[1]) == 22
