@@ -32,6 +32,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: BF16 dense (~2.5 PF)
+SPLIT_PRODUCTS = 6              # bf16 MFMA products per fp32 product in the 3xbf16-split kernels (csrc/igemm_split.h)
 DEPTH, B_LOCAL, T, HW = 18, 16, 16, 112
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 0.0, 0.0)
 NTXENT_WEIGHT = 1.0
@@ -169,20 +171,39 @@ def main():
         k_ms = timer.mean_ms()
         flops = 2.0 * 144 * 64 * 9 * (2 * args.batch * T * (HW // 2) * (HW // 2))   # algorithmic, per launch
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # which kernel variant the library runs for that geometry (autotuned per geometry)
+        import ctypes
+        from cstp_amd import _lib
+        from cstp_amd.ops import _desc
+        tile = (ctypes.c_int32 * 4)()
+        d_s1 = _desc((2 * args.batch, 64, T, HW // 2, HW // 2), (144, 64, 1, 3, 3), (1, 1, 1), (0, 1, 1))
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(d_s1), 0, tile), "cstp_conv3d_query_tile")
+        split = bool(tile[2])
+        # fp32-equivalent peak of the kernel that ran: native f32 MFMA 157.3 TF/s; the split kernel issues six bf16 MFMA
+        # products per fp32 product, so its ceiling is the bf16 dense peak / 6 (the algorithmic FLOPs stay the fp32 ones)
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else F32_MFMA_PEAK_TFLOPS
+        kname = ("igemm_k1s<%d,fwd> (3xbf16-split, %dx%d tile, bf16 MFMA 16x16x32 x6, f32 accumulate)" % (tile[0] // 16, tile[0], tile[1])
+                 if split else "igemm_k1 (native f32 MFMA, %dx%d tile)" % (tile[0], tile[1]))
         line = {
             "metric": "pretrain clips/sec (16x112x112)", "value": clips_s, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("fp32 throughout; GEMM-shaped kernels autotuned per layer between the native f32 MFMA and fp32 "
+                           "operands split exactly into 3 bf16 terms with 6 bf16-MFMA products and f32 accumulation "
+                           "(4e-7 rms from fp64 per convolution, same as the native path; CSTP_GEMM=f32 forces native)"),
             "config": {"workload": "r21d_byol R(2+1)D-%d, B=%d clip pairs/GPU 3x%dx%dx%d, BYOL + NT-Xent(all-gather) + "
                                    "overlap-rate heads, loss_weight 0.1 1 1 0 0, clip 18, SGD; random-init weights"
                                    % (args.depth, args.batch, T, HW, HW),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak,
+                         "peak_note": ("bf16 dense 2516.6 TF/s / 6 MFMA products per fp32 product" if split
+                                       else "f32 MFMA dense"),
+                         "frac_of_native_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH) else None,
                          "algorithmic_bytes_per_launch": 4.0 * (2 * args.batch * T * (HW // 2) * (HW // 2)) * (64 + 144)
                          + 4.0 * 144 * 64 * 9,
-                         "kernel": "igemm_k1<9,1,fwd,M16> spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
+                         "kernel": kname + "; spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
                          "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
                          "algorithmic_gflop_per_launch": flops / 1e9},
         }

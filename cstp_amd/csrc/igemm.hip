@@ -696,6 +696,10 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+}  // namespace cstp
+#include "igemm_split.h"
+namespace cstp {
+
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
   int best = 1;
   double bestc = 1e30;
@@ -707,8 +711,10 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
   return best;
 }
 
-struct Tile { int mt, wm, m16, tpb; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
-static inline int tile_bm(const Tile& t) { return t.m16 ? 16 * t.mt : 32 * t.mt * t.wm; }
+// sp = 1: the 3xbf16-split kernel igemm_k1s (igemm_split.h), tile (16*mt) x 128, 512 threads
+struct Tile { int mt, wm, m16, tpb, sp; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
+static inline int tile_bm(const Tile& t) { return (t.m16 || t.sp) ? 16 * t.mt : 32 * t.mt * t.wm; }
+static inline int tile_bn(const Tile& t) { return t.sp ? 128 : 32 * (4 / t.wm); }
 
 // K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
 // matrix pipes, so time ~ max blocks per CU x work per block); per-block work ~ BM x BN (K is fixed);
@@ -719,6 +725,7 @@ static Tile pick_tile(int M, long npos, int nclass) {
   static const char* ov = getenv("CSTP_TILE");
   if (ov != nullptr) {
     int mt = 0, wm = 0, tpb = 1;
+    if (ov[0] == 's' && sscanf(ov + 1, "%d", &mt) == 1 && mt >= 1 && mt <= 9) return Tile{mt, 1, 0, 1, 1};   // "s9": split kernel
     if (sscanf(ov, "%d,%d,%d", &mt, &wm, &tpb) >= 2 && mt >= 1 &&
         ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
       return Tile{mt, wm, 0, tpb == 2 ? 2 : 1};
@@ -797,12 +804,18 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // forward: M = k, gather channels = c
   if (!lookup_tuned(d, 0, p.f_t)) p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
   p.f_straddle = (d.c < 8);
+  // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
+  const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
+  const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
+  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || (p.f_t.mt != 4 && p.f_t.mt != 8 && p.f_t.mt != 9)))
+    p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
   p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
+  if (p.d_t.sp && (!y_small || p.ntaps > 27 || (p.d_t.mt != 4 && p.d_t.mt != 8 && p.d_t.mt != 9))) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -823,10 +836,12 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
 static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   // packed-operand rows are padded to the tile height (<= 160): size for the tallest padding so that any tile
   // (heuristic or tuned later) fits the workspace the caller sized once
-  size_t f = (size_t)p.f_Kp * ((size_t)d.k + 160), g = (size_t)p.d_Kp * ((size_t)d.c + 160), w = (size_t)d.k * p.w_Jp;
+  // (the split kernels' packed operand is three bf16 planes = 6 bytes per element)
+  size_t f = (size_t)p.f_Kp * ((size_t)d.k + 160) * 6, g = (size_t)p.d_Kp * ((size_t)d.c + 160) * 6;
+  size_t w = (size_t)d.k * p.w_Jp * sizeof(float);
   size_t m = f > g ? f : g;
   if (w > m) m = w;
-  return align_up(m * sizeof(float), 256);
+  return align_up(m, 256);
 }
 
 template <bool DGRAD, bool STRADDLE, bool XFORM, int TPB>
@@ -888,6 +903,18 @@ static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const flo
 #undef CSTP_K2
 }
 
+template <bool DGRAD>
+static void launch_k1s(int mt, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src, const float* bias,
+                       float* out, int ntx, int ntm) {
+#define CSTP_K1S(MT_) hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm)
+  switch (mt) {
+    case 4: CSTP_K1S(4); break;
+    case 8: CSTP_K1S(8); break;
+    default: CSTP_K1S(9); break;
+  }
+#undef CSTP_K1S
+}
+
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
 struct InAffine { const float2* ss; int npg, groups, relu; };
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
@@ -928,20 +955,26 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp,
-                     p.f_Kp, 0);
+  const bool f_split = p.f_t.sp && !p.f_straddle && (in_affine == nullptr || in_affine->scale_shift == nullptr);
+  if (f_split)
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned short*>(ws), d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp, p.f_Kp / 16, 0);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp,
+                       p.f_Kp, 0);
   Geom g;
   g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.f_Cp; g.M = d.k; g.Mp = p.f_Mp; g.Ktot = p.ntaps * p.f_Cp;
   const int npos = d.n * p.Do * p.Ho * p.Wo;
-  const int f_bm = tile_bm(p.f_t), f_bn = 32 * (4 / p.f_t.wm);
+  const int f_bm = tile_bm(p.f_t), f_bn = tile_bn(p.f_t);
   const int ntx = cdiv(npos, f_bn), ntm = cdiv(d.k, f_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
-  if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
+  if (f_split) launch_k1s<false>(p.f_t.mt, grid, s, g, reinterpret_cast<const uint4*>(ws), x, bias, y, ntx, ntm);
+  else if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   else if (ia.ss) launch_k1<false, false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, ia.ss, ia.npg, ia.relu);
   else launch_k1<false, false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
@@ -960,8 +993,13 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
   const size_t tot = (size_t)p.d_Kp * p.d_Mp;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp,
-                     p.d_Kp, 1);
+  const bool d_split = p.d_t.sp != 0;
+  if (d_split)
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned short*>(ws), d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp, p.d_Kp / 16, 1);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp,
+                       p.d_Kp, 1);
   Geom g;
   g.Cs = d.k; g.Ds = p.Do; g.Hs = p.Ho; g.Ws = p.Wo;     // gather from dy
   g.Nb = d.n; g.Dp = d.d; g.Hp = d.h; g.Wp = d.w;         // FULL x dims; classes subsample inside
@@ -969,10 +1007,11 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   g.Cp = p.d_Cp; g.M = d.c; g.Mp = p.d_Mp; g.Ktot = p.ntaps * p.d_Cp;
   const int nclass = d.st * d.sh * d.sw;
   const int npos_max = d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw);
-  const int d_bm = tile_bm(p.d_t), d_bn = 32 * (4 / p.d_t.wm);
+  const int d_bm = tile_bm(p.d_t), d_bn = tile_bn(p.d_t);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
-  launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);
+  if (d_split) launch_k1s<true>(p.d_t.mt, grid, s, g, reinterpret_cast<const uint4*>(ws), dy, nullptr, dx, ntx, ntm);
+  else launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -1028,6 +1067,19 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   return 0;
 }
 
+extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4) {
+  CSTP_REQUIRE(desc && out4, "null argument");
+  CSTP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (backward_data)");
+  ConvPlan p;
+  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  const Tile& t = mode == 0 ? p.f_t : p.d_t;
+  out4[0] = tile_bm(t);
+  out4[1] = tile_bn(t);
+  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? 1 : 0;
+  out4[3] = t.tpb == 2 ? 2 : 1;
+  return 0;
+}
+
 extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src,
                                     const float* w, float* out, void* ws, size_t ws_bytes, int32_t iters) {
   CSTP_REQUIRE(desc && src && w && out && ws, "null argument");
@@ -1077,12 +1129,20 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
-  Tile cand[18] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
+  Tile cand[24] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
                    {9, 1, 1, 1}};
   int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
   if (!straddle) {       // the same tiles with two K-tiles per barrier
     const int n1 = ncand;
     for (int i = 0; i < n1; ++i) { cand[ncand] = cand[i]; cand[ncand].tpb = 2; ++ncand; }
+  }
+  // the 3xbf16-split kernels (fp32-equivalent products on the bf16 matrix cores), unless CSTP_GEMM=f32
+  static const char* gemm_env = getenv("CSTP_GEMM");
+  const bool allow_split = !(gemm_env != nullptr && strcmp(gemm_env, "f32") == 0);
+  if (allow_split && !straddle && d.kt * d.kh * d.kw <= 27) {
+    cand[ncand++] = Tile{4, 1, 0, 1, 1};
+    if (M > 64) cand[ncand++] = Tile{8, 1, 0, 1, 1};
+    if (M > 128) cand[ncand++] = Tile{9, 1, 0, 1, 1};
   }
   hipStream_t s = as_stream(stream);
   hipEvent_t e0, e1;

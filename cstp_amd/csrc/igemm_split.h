@@ -1,0 +1,526 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with fp32-equivalent arithmetic ("3xbf16 split").
+//
+// Every fp32 operand value x is written EXACTLY-to-2^-25 as the sum of three bf16 numbers
+//     x = hi + mid + lo,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (each difference is exact in fp32)
+// and a product a*b is accumulated in fp32 from the six partial products whose weight is >= 2^-16 relative:
+//     a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)            (dropped: am*bl, al*bm, al*bl <= 3 * 2^-24 |ab|)
+// i.e. the error per product is of the size of ONE fp32 rounding.  Six v_mfma_f32_16x16x32_bf16 (16 cycles each for
+// 16*16*32 MACs) replace the 8 v_mfma_f32_16x16x4_f32 (32 cycles each) of the native fp32 path: 96 vs 256 matrix-pipe
+// cycles per 16x16x32 block product, a 2.67x higher ceiling (2516 / 6 = 419 TFLOP/s fp32-equivalent on MI355X).
+//
+// K1S  igemm_k1s<MT, DGRAD>:  out[m][n] = sum_k W[k][m] * Xcol[k][n]   (forward / data gradient, see igemm.hip)
+//   block = 512 threads = 8 waves, tile (16*MT) x 128 positions, K-tile 32 = two independent 16-channel groups
+//   (each group lies inside one filter tap, so the per-tap channel count only needs padding to 16);
+//   the waves are SPECIALISED: waves 4-7 (one per SIMD) are producers -- they gather the fp32 operand, split it and
+//   stage both operands into the LDS double buffer, with two K-tiles of global loads in flight per thread -- and
+//   waves 0-3 (one per SIMD) are consumers that only read fragments
+//   and issue MFMAs, so on every SIMD the vector ALU work of the split runs in the issue slots the matrix pipe leaves
+//   free instead of alternating with it;
+//   weights arrive pre-split (pack_weights_split_kernel: [group][m][plane][16] bf16), activations are gathered as fp32
+//   (coalesced along positions), split in registers and stored to LDS as bf16 planes;
+//   LDS image per operand row (one m or one position): [plane0: 32 k][plane1][plane2] = 192 B with the four 16-byte k-chunks of a plane XOR-swizzled by the row, which makes
+//   both the 16-byte fragment reads of the MFMA (16 rows x one 8-k slice per quarter wave) and the staging stores
+//   bank-conflict free;  consumer wave w owns columns 32w .. 32w+31 (two 16-column tiles) of all MT row tiles.
+#pragma once
+
+namespace cstp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SPL_ROW = 12;   // uint4 (16 B) per LDS operand row: 3 planes x 64 B, no padding
+// 16-byte k-chunk c (0..3) of a plane sits at c ^ spl_swz(row): with the non-contiguous 16-lane groups of ds_read_b128 and the
+// 8-lane groups of ds_write_b128 this makes BOTH the fragment reads and the staging stores bank-conflict free (searched
+// exhaustively over row strides 12..19 x XOR swizzles; stride 13 unswizzled reads 2-way, stride 14 writes 2-way).
+__device__ __forceinline__ int spl_swz(int row) { return (row >> 1) & 3; }
+
+// two fp32 -> three packed bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  f32x2 v = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  f32x2 r = v - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+  f32x2 s = r - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer resource (stride 0, bounds-checked against `bytes`): out-of-range loads return 0
+__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+// Loads issued behind the compiler's back (it does not know these are memory operations and inserts no waits):
+// every value they produce MUST pass through wait_loads<> before its first use -- and must not be copied, converted
+// or repacked before that (a v_mov of a register whose load is still in flight reads stale data), so the staging
+// arrays keep exactly the types the asm writes.
+#ifndef CSTP_DIAG
+#define CSTP_DIAG 0      // 1: consumers only synchronise (producer-bound time); 2: producers only synchronise
+#endif
+#ifndef CSTP_CONS_PIPE
+#define CSTP_CONS_PIPE 0   // 1: consumer reads fragments two row tiles ahead with sched_barrier pins -- measured SLOWER
+                           // (1.96 vs 1.82 ms on the S1 layer) than letting hipcc place the reads, kept for reference
+#endif
+#ifndef CSTP_PROD_STEADY
+#define CSTP_PROD_STEADY 1 // producer steady-state loop without conditional loads (counted vmcnt waits)
+#endif
+#ifndef CSTP_ASM_LOADS
+#define CSTP_ASM_LOADS 0
+#endif
+__device__ __forceinline__ void buf_load_x4(u32x4& d, unsigned voff, u32x4 rs, unsigned soff) {
+#if CSTP_ASM_LOADS
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
+  d = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, (int)rs.z, (int)rs.w), voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ void buf_load_x1(float& d, unsigned voff, u32x4 rs, unsigned soff) {
+#if CSTP_ASM_LOADS
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
+  d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, (int)rs.z, (int)rs.w), voff, soff, 0));
+#endif
+}
+// s_waitcnt vmcnt(N) that the register set depends on (N = loads issued after the set's own)
+template <int N, int NA>
+__device__ __forceinline__ void wait_loads(u32x4 (&ra)[NA], float (&rb)[16]) {
+  static_assert(NA >= 2 && NA <= 7, "register set size");
+#if !CSTP_ASM_LOADS
+  return;                                            // compiler-visible loads: it inserts the waits itself
+#endif
+  // operands: NA quads + 16 floats, each tied in place ("+v"); unused quad slots alias ra[0] harmlessly via the switch
+#define CSTP_B16 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]), \
+                 "+v"(rb[8]), "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]), "+v"(rb[12]), "+v"(rb[13]), "+v"(rb[14]), "+v"(rb[15])
+  if constexpr (NA == 2)
+    asm volatile("s_waitcnt vmcnt(%18)" : "+v"(ra[0]), "+v"(ra[1]), CSTP_B16 : "n"(N) : "memory");
+  else if constexpr (NA == 3)
+    asm volatile("s_waitcnt vmcnt(%19)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), CSTP_B16 : "n"(N) : "memory");
+  else if constexpr (NA == 4)
+    asm volatile("s_waitcnt vmcnt(%20)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), CSTP_B16 : "n"(N) : "memory");
+  else if constexpr (NA == 5)
+    asm volatile("s_waitcnt vmcnt(%21)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), CSTP_B16 : "n"(N) : "memory");
+  else if constexpr (NA == 6)
+    asm volatile("s_waitcnt vmcnt(%22)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), CSTP_B16 : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%23)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), CSTP_B16 : "n"(N) : "memory");
+#undef CSTP_B16
+}
+
+// weights: native [k_out][c_in][taps] -> split GEMM operand  wps[group = k/16][m (Mp)][plane (3)][k%16]  bf16,
+// k = tap*Cp + c (forward, m = k_out) or tap*Cp + k_out (dgrad, m = c_in); zero padded.
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wps, int kout, int cin,
+                                          int ntaps, int Cp, int Mp, int ngroups, int dgrad) {
+  const size_t total = (size_t)ngroups * Mp * 8;      // one thread per (group, m, pair of k)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kp = (int)(i & 7);
+    const size_t gm = i >> 3;
+    const int m = (int)(gm % Mp), grp = (int)(gm / Mp);
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = grp * 16 + kp * 2 + e;
+      const int tap = k / Cp, c = k - tap * Cp;
+      float x = 0.f;
+      if (tap < ntaps) {
+        if (!dgrad) {
+          if (m < kout && c < cin) x = w[((size_t)m * cin + c) * ntaps + tap];
+        } else {
+          if (m < cin && c < kout) x = w[((size_t)c * cin + m) * ntaps + tap];
+        }
+      }
+      v[e] = x;
+    }
+    unsigned h, mm, l;
+    split2(v[0], v[1], h, mm, l);
+    unsigned* dst = reinterpret_cast<unsigned*>(wps + gm * 48) + kp;   // 48 bf16 per (group, m): 3 planes x 16
+    dst[0] = h;
+    dst[8] = mm;
+    dst[16] = l;
+  }
+}
+
+template <int MT, bool DGRAD>
+__global__ void __launch_bounds__(512)
+igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
+          float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
+  constexpr int BM = 16 * MT, BN = 128;
+  constexpr int A_CH = BM * 6;                      // 16-byte chunks per A half-tile (one 16-k group)
+  __shared__ uint4 As[2][BM * SPL_ROW];
+  __shared__ uint4 Bs[2][BN * SPL_ROW];
+  __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // in an SGPR: everything derived from it stays scalar
+
+  // XCD-aware tile order (see igemm_k1)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mtile = slot % n_tiles_m;
+  const int chunk = (n_tiles_x + 7) >> 3;
+  const int nt_in = slot / n_tiles_m;
+  const int ntile = xcd * chunk + nt_in;
+  if (nt_in >= chunk || ntile >= n_tiles_x) return;
+
+  int zt = 0, zh = 0, zw = 0;
+  int Dp = g.Dp, Hp = g.Hp, Wp = g.Wp;
+  if (DGRAD) {
+    int z = blockIdx.y;
+    zw = z % g.sw; z /= g.sw;
+    zh = z % g.sh; zt = z / g.sh;
+    Dp = (g.Dp - zt + g.st - 1) / g.st;
+    Hp = (g.Hp - zh + g.sh - 1) / g.sh;
+    Wp = (g.Wp - zw + g.sw - 1) / g.sw;
+  }
+  const int npos = g.Nb * Dp * Hp * Wp;
+  const int n0 = ntile * BN;
+  if (n0 >= npos) return;
+  const int m0 = mtile * BM;
+
+  const int khw = g.kh * g.kw, ntaps = g.kt * khw;
+  const int gpt = g.Cp >> 4;                         // 16-channel groups per tap
+
+  // ---- the tap sequence (block-uniform)
+  int nvt = ntaps;
+  if (DGRAD) {
+    if (t == 0) {
+      int c = 0;
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+        const int et = zt + g.pt - dt, eh = zh + g.ph - dh, ew = zw + g.pw - dw;
+        if ((et % g.st) == 0 && (eh % g.sh) == 0 && (ew % g.sw) == 0) vtap[c++] = tp;
+      }
+      vtap[27] = c;
+    }
+    __syncthreads();
+    nvt = __builtin_amdgcn_readfirstlane(vtap[27]);
+  }
+  const int ngroups = nvt * gpt;
+  const int ntiles = (ngroups + 1) >> 1;
+
+  if (wave >= 4) {
+    // =================================== producer waves: gather, split, stage ===================================
+    // 256 threads: thread (col, g2) gathers the 16 channels of group g2 (waves 4,5: first 16-k group of the K-tile,
+    // waves 6,7: second) for ONE position and 1/128 of that group's A half-tile.
+    // All global reads are raw BUFFER loads: the wave-uniform part of every address (channel block, A half-tile) rides
+    // in the scalar offset, the per-thread part is a VGPR that only changes with the filter tap, and a masked element
+    // (halo / padding position, missing half-tile) is an out-of-range offset that the hardware answers with 0 -- no
+    // address arithmetic and no selects in the loop; the vector ALU only does the bf16 split.
+    // TWO K-tiles of raw operands are in flight per thread.  The loads are issued from inline asm and waited for
+    // with explicit counted s_waitcnt vmcnt(23) (= "all but the younger tile's 23 loads"): the compiler's own
+    // accounting waits for vmcnt(0) here, which exposes the full memory latency every tile.
+    const int tp_ = t - 256;
+    const int col = tp_ & 127, g2 = (wave - 4) >> 1;
+    const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+    const bool nvalid = (n0 + col) < npos;
+    int nb, npd, nph, npw;
+    {
+      int n = nvalid ? (n0 + col) : 0;
+      npw = n % Wp; n /= Wp;
+      nph = n % Hp; n /= Hp;
+      npd = n % Dp; nb = n / Dp;
+    }
+    constexpr unsigned OOB = 0x80000000u;            // host guarantees both buffers are < 2 GiB
+    const unsigned src_b4 = (unsigned)((size_t)nb * g.Cs * DHWs) * 4u;
+    const u32x4 rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 4));
+    const u32x4 rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * 96));
+    // A half-tile of my group: 16-byte chunk idc = col + 128 j of BM*6, j = 0..A_IT-1 (the last may be partial)
+    constexpr int A_IT = (A_CH + 127) / 128;
+    static_assert(A_IT <= 7, "A staging holds at most 7 chunks per producer thread");
+    constexpr int NLOADS = A_IT + 16;                // loads per thread and K-tile
+    const bool a_last_ok = col + 128 * (A_IT - 1) < A_CH;
+    const unsigned va_full = (unsigned)col * 16u;
+    const unsigned va_last = a_last_ok ? va_full : OOB;
+    int a_lds[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+      int idc = col + 128 * j;
+      if (idc >= A_CH) idc = 0;
+      const int row = idc / 6, w6 = idc - row * 6;
+      a_lds[j] = row * SPL_ROW + (w6 >> 1) * 4 + ((g2 * 2 + (w6 & 1)) ^ spl_swz(row));
+    }
+    const int b_lds = col * SPL_ROW;
+    const int bq0 = (g2 * 2) ^ spl_swz(col), bq1 = (g2 * 2 + 1) ^ spl_swz(col);
+    const unsigned ch4 = (unsigned)DHWs * 4u;         // byte stride between channels
+
+    // my group sequence: e = g2, g2 + 2, ... ; (ord, cg) = (tap ordinal, 16-channel block inside the tap), kept
+    // incrementally (no division in the loop)
+    int ord = g2 / gpt, cg = g2 - ord * gpt;
+    int e = g2;
+    unsigned vbj[16];                                 // per-thread byte offsets of the 16 channels at the current tap
+    auto set_tap = [&]() __attribute__((always_inline)) {
+      const int tp = DGRAD ? __builtin_amdgcn_readfirstlane(vtap[ord < nvt ? ord : 0]) : ord;
+      const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+      int id, ih, iw;
+      if (DGRAD) {
+        const int et = zt + g.pt - dt, eh = zh + g.ph - dh, ew = zw + g.pw - dw;
+        id = npd + et / g.st; ih = nph + eh / g.sh; iw = npw + ew / g.sw;
+      } else {
+        id = npd * g.st - g.pt + dt; ih = nph * g.sh - g.ph + dh; iw = npw * g.sw - g.pw + dw;
+      }
+      const bool ok = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+      const unsigned vb = ok ? src_b4 + (unsigned)(id * HWs + ih * g.Ws + iw) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) vbj[j] = vb + ch4 * j;
+      return tp;
+    };
+    int tap = set_tap();
+
+    u32x4 ra0[A_IT], ra1[A_IT];
+    float rb0[16], rb1[16];
+
+    // issue the loads of my current group into the given register set, then advance to my next group
+    auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[16]) __attribute__((always_inline)) {
+      const bool have = e < ngroups;                  // uniform; a missing group loads zeros (OOB offsets)
+      const unsigned sa = (unsigned)(((size_t)(tap * gpt + cg) * g.Mp + m0) * 96);
+      const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
+#pragma unroll
+      for (int j = 0; j < A_IT; ++j) buf_load_x4(ra[j], j == A_IT - 1 ? vlast : vfull, rs_w, sa + 2048u * j);
+      const unsigned sb = have ? (unsigned)(cg << 4) * ch4 : OOB;   // scalar part: first channel of the block
+#pragma unroll
+      for (int j = 0; j < 16; ++j) buf_load_x1(rb[j], have ? vbj[j] : OOB, rs_src, have ? sb : 0u);
+      e += 2;
+      cg += 2;
+      if (cg >= gpt) {                                // uniform: next tap(s)
+        do { cg -= gpt; ++ord; } while (cg >= gpt);
+        tap = set_tap();
+      }
+    };
+
+    auto split_store = [&](int buf, u32x4 (&ra)[A_IT], float (&rb)[16]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < A_IT; ++j)
+        if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
+      uint4 ph[2], pm[2], pl[2];
+      unsigned hh, mm, ll;
+#define CSTP_SPLIT(J, DST, F) split2(rb[J], rb[(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
+      CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
+      CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
+#undef CSTP_SPLIT
+      uint4* brow = &Bs[buf][b_lds];
+      brow[bq0] = ph[0]; brow[bq1] = ph[1];
+      brow[4 + bq0] = pm[0]; brow[4 + bq1] = pm[1];
+      brow[8 + bq0] = pl[0]; brow[8 + bq1] = pl[1];
+    };
+
+    // tile i lives in set (i & 1) and is staged into LDS buffer (i & 1) during the consumption of tile i - 1.
+    // The steady-state loop contains NO conditional load: the compiler's s_waitcnt accounting then knows that exactly
+    // one younger tile (NLOADS loads) is outstanding when a set is consumed and emits counted waits; with a load under
+    // `if` it must assume the younger loads may not exist and waits for everything, exposing the memory latency.
+    int i = 0;
+#if CSTP_DIAG == 2
+    __syncthreads();
+    for (; i < ntiles; ++i) __syncthreads();
+    return;
+#endif
+    if (CSTP_PROD_STEADY && ntiles >= 4) {
+      issue_loads(ra0, rb0);                          // tile 0
+      issue_loads(ra1, rb1);                          // tile 1
+      wait_loads<NLOADS>(ra0, rb0);
+      split_store(0, ra0, rb0);
+      issue_loads(ra0, rb0);                          // tile 2
+      __syncthreads();
+      while (i + 4 < ntiles) {
+        wait_loads<NLOADS>(ra1, rb1);
+        split_store(1, ra1, rb1);                     // tile i+1
+        issue_loads(ra1, rb1);                        // tile i+3
+        __syncthreads();
+        wait_loads<NLOADS>(ra0, rb0);
+        split_store(0, ra0, rb0);                     // tile i+2
+        issue_loads(ra0, rb0);                        // tile i+4
+        __syncthreads();
+        i += 2;
+      }
+    } else {
+      if (ntiles > 0) issue_loads(ra0, rb0);
+      if (ntiles > 1) issue_loads(ra1, rb1);
+      if (ntiles > 0) {
+        if (ntiles > 1) wait_loads<NLOADS>(ra0, rb0); else wait_loads<0>(ra0, rb0);
+        split_store(0, ra0, rb0);
+        if (ntiles > 2) issue_loads(ra0, rb0);
+      }
+      __syncthreads();
+    }
+    for (; i < ntiles; i += 2) {                      // tail (and the whole loop of short reductions)
+      if (i + 1 < ntiles) {                           // stage tile i+1 (set 1) while tile i is consumed
+        if (i + 2 < ntiles) wait_loads<NLOADS>(ra1, rb1); else wait_loads<0>(ra1, rb1);
+        split_store(1, ra1, rb1);
+        if (i + 3 < ntiles) issue_loads(ra1, rb1);
+      }
+      __syncthreads();
+      if (i + 1 >= ntiles) break;
+      if (i + 2 < ntiles) {                           // stage tile i+2 (set 0) while tile i+1 is consumed
+        if (i + 3 < ntiles) wait_loads<NLOADS>(ra0, rb0); else wait_loads<0>(ra0, rb0);
+        split_store(0, ra0, rb0);
+        if (i + 4 < ntiles) issue_loads(ra0, rb0);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ===================================== consumer waves: LDS -> MFMA -> output =====================================
+  // lane l feeds A[m = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][n = l&15]; wave w owns columns 32w .. 32w+31
+  const int wn = wave;
+  const int fr = lane & 15, fk = lane >> 4;
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+
+#if CSTP_DIAG == 1
+  __syncthreads();
+  for (int i = 0; i < ntiles; ++i) __syncthreads();
+  if (ntiles >= 0) return;
+#endif
+#if CSTP_CONS_PIPE
+  // Fragments are read two row tiles AHEAD of the MFMAs that use them, and the next K-tile's first fragments are read
+  // (right after the barrier that publishes it) under the last two row tiles' MFMAs, so the matrix pipe never waits
+  // for an LDS round trip.  sched_barrier pins that order (the scheduler otherwise sinks each read to its use).
+  constexpr int NS = (MT % 3 == 0) ? 3 : 4;          // A fragment sets in rotation; MT % NS == 0 keeps the rotation per tile
+  static_assert(MT % NS == 0 && MT >= 4, "row-tile count must be a multiple of the fragment-set count");
+  bf16x8 Bf[2][2][3];                                 // [set][column tile][plane]
+  bf16x8 Af[NS][3];
+  const int frag = fr * SPL_ROW + (fk ^ spl_swz(fr));
+  auto load_B = [&](int buf, int set) __attribute__((always_inline)) {
+    const uint4* Bb = &Bs[buf][wn * 32 * SPL_ROW + frag];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Bf[set][c][p] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4 * p]);
+  };
+  auto load_A = [&](int buf, int mt, int set) __attribute__((always_inline)) {
+    const uint4* Ab = &As[buf][mt * 16 * SPL_ROW + frag];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) Af[set][p] = __builtin_bit_cast(bf16x8, Ab[4 * p]);
+  };
+  auto mma_row = [&](int mt, int aset, int bset) __attribute__((always_inline)) {
+    const bf16x8 ah = Af[aset][0], am = Af[aset][1], al = Af[aset][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8 bh = Bf[bset][c][0], bm = Bf[bset][c][1], bl = Bf[bset][c][2];
+      f32x4 a = acc[mt][c];
+      // smallest terms first
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
+      acc[mt][c] = a;
+    }
+  };
+  // one K-tile: `bcur` holds its B fragments, A sets 0 and 1 its first two row tiles.  The reads for the NEXT tile are
+  // unconditional (after the last tile they fetch stale LDS that nobody uses).
+  auto tile = [&](int buf, int bcur) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt + 2 < MT) {
+        load_A(buf, mt + 2, (mt + 2) % NS);
+      } else if (mt + 2 == MT) {
+        __syncthreads();                              // this tile's LDS reads are all issued; the next tile is published
+        load_B(buf ^ 1, bcur ^ 1);
+        load_A(buf ^ 1, 0, 0);
+      } else {
+        load_A(buf ^ 1, 1, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_row(mt, mt % NS, bcur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  __syncthreads();
+  load_B(0, 0);
+  load_A(0, 0, 0);
+  load_A(0, 1, 1);
+  for (int i = 0; i < ntiles; i += 2) {
+    tile(0, 0);
+    if (i + 1 < ntiles) tile(1, 1);
+  }
+
+#else
+  __syncthreads();
+  {
+    int buf = 0;
+    for (int i = 0; i < ntiles; ++i) {
+      const uint4* Bb = &Bs[buf][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
+      const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
+      bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW]);
+        bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4]);
+        bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 8]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x4 a = acc[mt][c];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a, 0, 0, 0);
+          acc[mt][c] = a;
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#endif
+
+  // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg, two column tiles per wave; lane groups q and q^1
+  // swap one register so that 32 consecutive lanes hold 32 consecutive columns of ONE row (whole 128-byte lines)
+  const int lcol = lane & 31;
+  const int n = n0 + wn * 32 + lcol;
+  const int q = lane >> 4;
+  const bool odd = (q & 1) != 0;
+  size_t obase = 0, cstride = 0;
+  const bool nok = n < npos;
+  if (nok) {
+    if (DGRAD) {
+      int qq = n;
+      const int pw = qq % Wp; qq /= Wp;
+      const int ph = qq % Hp; qq /= Hp;
+      const int pd = qq % Dp; const int b = qq / Dp;
+      const int HWf = g.Hp * g.Wp;
+      cstride = (size_t)g.Dp * HWf;
+      obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
+    } else {
+      const int S = Dp * Hp * Wp;
+      const int b = n / S, sp = n - b * S;
+      cstride = (size_t)S;
+      obase = (size_t)b * g.M * cstride + sp;
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
+      const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
+      const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
+      float ve = odd ? recv : v0;
+      float vo = odd ? v1 : recv;
+      if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
+      if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
+    }
+  }
+}
+
+}  // namespace cstp

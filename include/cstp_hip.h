@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 6
+#define CSTP_ABI_VERSION 7
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -70,11 +70,20 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
                                 const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                 size_t ws_bytes);
 
+/* Which kernel variant the next forward (mode 0) / backward_data (mode 1) call with this descriptor will run:
+ * out[0] = rows per block tile, out[1] = positions per block tile, out[2] = 1 when it is the 3xbf16-split kernel (fp32
+ * operands split into three bf16 terms, six bf16 MFMA products per fp32 product, f32 accumulate -- fp32-equivalent
+ * arithmetic on the bf16 matrix cores, csrc/igemm_split.h) and 0 for the native f32 MFMA kernel, out[3] = K-tiles per
+ * barrier.  Reporting only (bench.py names the kernel and picks the roofline peak with it). */
+int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
+
 /* Optional one-off tuning, OUTSIDE graph capture: times the tile shapes of the forward (mode 0: src = x, w = weights,
  * out = y), data-gradient (mode 1: src = dy, w = weights, out = dx) or weight-gradient (mode 2: src = x, w = dy,
  * out = dw; row-tile height x split-K block count) kernel for this geometry on `stream` (this call DOES synchronise)
- * and remembers the fastest in a process-wide table that later calls with the same descriptor consult.  Results
- * are bit-identical for every tile shape; without tuning an analytic choice is used.  `out` is overwritten. */
+ * and remembers the fastest in a process-wide table that later calls with the same descriptor consult.  The native
+ * f32 tiles give bit-identical results among themselves; the 3xbf16-split tiles (candidates unless the environment says
+ * CSTP_GEMM=f32) differ from them in the last bits (both sit ~4e-7 rms from the fp64 result per convolution,
+ * tools/split_accuracy.py).  Without tuning an analytic native-f32 choice is used.  `out` is overwritten. */
 int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src, const float* w,
                          float* out, void* ws, size_t ws_bytes, int32_t iters);
 

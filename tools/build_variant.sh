@@ -1,0 +1,8 @@
+#!/bin/bash
+# build a kernel-library variant into build_ab/<name>.so with extra -D flags:  tools/build_variant.sh name -DFOO=1 ...
+set -e
+name=$1; shift
+mkdir -p build_ab
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -Iinclude -Icstp_amd/csrc "$@" -o build_ab/$name.so \
+  cstp_amd/csrc/igemm.hip cstp_amd/csrc/bn.hip cstp_amd/csrc/misc.hip
+echo built build_ab/$name.so
