@@ -715,6 +715,7 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
 struct Tile { int mt, wm, m16, tpb, sp; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
 static inline int tile_bm(const Tile& t) { return (t.m16 || t.sp) ? 16 * t.mt : 32 * t.mt * t.wm; }
 static inline int tile_bn(const Tile& t) { return t.sp ? 128 : 32 * (4 / t.wm); }
+static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 
 // K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
 // matrix pipes, so time ~ max blocks per CU x work per block); per-block work ~ BM x BN (K is fixed);
@@ -725,7 +726,7 @@ static Tile pick_tile(int M, long npos, int nclass) {
   static const char* ov = getenv("CSTP_TILE");
   if (ov != nullptr) {
     int mt = 0, wm = 0, tpb = 1;
-    if (ov[0] == 's' && sscanf(ov + 1, "%d", &mt) == 1 && mt >= 1 && mt <= 9) return Tile{mt, 1, 0, 1, 1};   // "s9": split kernel
+    if (ov[0] == 's' && sscanf(ov + 1, "%d", &mt) == 1 && split_mt_ok(mt)) return Tile{mt, 1, 0, 1, 1};   // "s9": split kernel
     if (sscanf(ov, "%d,%d,%d", &mt, &wm, &tpb) >= 2 && mt >= 1 &&
         ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
       return Tile{mt, wm, 0, tpb == 2 ? 2 : 1};
@@ -807,7 +808,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
-  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || (p.f_t.mt != 4 && p.f_t.mt != 8 && p.f_t.mt != 9)))
+  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_mt_ok(p.f_t.mt)))
     p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
@@ -815,7 +816,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
-  if (p.d_t.sp && (!y_small || p.ntaps > 27 || (p.d_t.mt != 4 && p.d_t.mt != 8 && p.d_t.mt != 9))) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_mt_ok(p.d_t.mt))) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -908,7 +909,11 @@ static void launch_k1s(int mt, dim3 grid, hipStream_t s, const Geom& g, const ui
                        float* out, int ntx, int ntm) {
 #define CSTP_K1S(MT_) hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm)
   switch (mt) {
+    case 2: CSTP_K1S(2); break;
+    case 3: CSTP_K1S(3); break;
     case 4: CSTP_K1S(4); break;
+    case 5: CSTP_K1S(5); break;
+    case 6: CSTP_K1S(6); break;
     case 8: CSTP_K1S(8); break;
     default: CSTP_K1S(9); break;
   }
@@ -1129,7 +1134,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
-  Tile cand[24] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
+  Tile cand[32] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
                    {9, 1, 1, 1}};
   int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
   if (!straddle) {       // the same tiles with two K-tiles per barrier
@@ -1140,9 +1145,14 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   static const char* gemm_env = getenv("CSTP_GEMM");
   const bool allow_split = !(gemm_env != nullptr && strcmp(gemm_env, "f32") == 0);
   if (allow_split && !straddle && d.kt * d.kh * d.kw <= 27) {
-    cand[ncand++] = Tile{4, 1, 0, 1, 1};
-    if (M > 64) cand[ncand++] = Tile{8, 1, 0, 1, 1};
-    if (M > 128) cand[ncand++] = Tile{9, 1, 0, 1, 1};
+    // row-tile heights 32..144; keep those that pad M by at most ~1/8 (and the two smallest paddings regardless)
+    static const int smt[] = {2, 3, 4, 5, 6, 8, 9};
+    int best_pad = 1 << 30;
+    for (int mt : smt) { const int pad = cdiv(M, 16 * mt) * 16 * mt - M; if (pad < best_pad) best_pad = pad; }
+    for (int mt : smt) {
+      const int pad = cdiv(M, 16 * mt) * 16 * mt - M;
+      if ((pad <= best_pad + M / 8) && ncand < 32) cand[ncand++] = Tile{mt, 1, 0, 1, 1};
+    }
   }
   hipStream_t s = as_stream(stream);
   hipEvent_t e0, e1;
