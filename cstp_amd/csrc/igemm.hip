@@ -790,7 +790,7 @@ struct ConvPlan {
   // dgrad
   Tile d_t; int d_Cp, d_Mp, d_Kp;
   // wgrad
-  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle;
+  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split;
 };
 
 static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
@@ -824,9 +824,23 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   p.w_straddle = (d.c < 8);
   p.w_mt = (CSTP_M16 && !p.w_straddle && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);   // 9 = nine 16-row tiles
   p.w_blocks = 2048;   // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set
+  p.w_split = false;
   {
     Tile wt;
-    if (lookup_tuned(d, 2, wt)) { p.w_mt = wt.m16 ? 9 : wt.mt; p.w_blocks = 256 * wt.wm; }
+    bool have_wt = lookup_tuned(d, 2, wt);
+    // developer override: CSTP_WTILE="s<mt>,<blocks/256>" forces the split weight-gradient kernel; unset in production
+    static const char* wov = getenv("CSTP_WTILE");
+    if (!have_wt && wov != nullptr && wov[0] == 's') {
+      int mt = 0, bl = 8;
+      if (sscanf(wov + 1, "%d,%d", &mt, &bl) >= 1 && (mt == 8 || mt == 9)) { wt = Tile{mt, bl, 0, 0, 1}; have_wt = true; }
+    }
+    if (have_wt) {
+      p.w_mt = wt.m16 ? 9 : wt.mt;
+      p.w_blocks = 256 * wt.wm;
+      // igemm_k2s (3xbf16 split): 128- or 144-row tiles, 31-bit buffer offsets
+      p.w_split = wt.sp && !p.w_straddle && x_small && y_small && (wt.mt == 8 || wt.mt == 9);
+      if (wt.sp && !p.w_split) p.w_mt = pick_mt(d.k);
+    }
   }
   p.w_Cp = p.w_straddle ? d.c : (int)align_up(d.c, 32);
   p.w_Jtot = p.ntaps * p.w_Cp;
@@ -1040,10 +1054,15 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;      // reduction over dy positions
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
+  InAffine ia;
+  if (parse_in_affine(in_affine, d, ia)) return 1;
+  // the split kernel has no fused input transform: a call that carries one runs the native kernel with its analytic tile
+  const bool w_split = p.w_split && ia.ss == nullptr;
+  if (p.w_split && !w_split) p.w_mt = (CSTP_M16 && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);
   const int npos = d.n * p.Do * p.Ho * p.Wo;
   const int bkn = CSTP_K2_BKN;
   const int kt_total = cdiv(npos, bkn);
-  const int ntm = cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
+  const int ntm = w_split ? cdiv(d.k, 16 * p.w_mt) : cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
   int splits = cdiv(p.w_blocks, ntm * ntj);
   if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
   if (splits < 1) splits = 1;
@@ -1051,10 +1070,13 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   splits = cdiv(kt_total, kt_per);
   dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
   const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-  InAffine ia;
-  if (parse_in_affine(in_affine, d, ia)) return 1;
 #define CSTP_K2_ARGS p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, ia.ss, ia.npg, ia.groups, ia.relu
-  if (p.w_straddle) {
+  if (w_split) {
+    if (p.w_mt == 9)
+      hipLaunchKernelGGL((igemm_k2s<9>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else
+      hipLaunchKernelGGL((igemm_k2s<8>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+  } else if (p.w_straddle) {
     if (v4) launch_k2<true, true, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
     else launch_k2<true, false, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
   } else if (ia.ss) {
@@ -1094,14 +1116,20 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   if (mode == 2) {
     // weight gradient (src = x, w = dy, out = dw): row-tile height x split-K block target
     const bool stem = d.c < 8;
-    Tile wc[16];
+    Tile wc[24];
     int nw = 0;
     const int base = pick_mt(d.k);
+    static const char* gemm_env2 = getenv("CSTP_GEMM");
+    const bool allow_split2 = !(gemm_env2 != nullptr && strcmp(gemm_env2, "f32") == 0);
     for (int blocks = 4; blocks <= 16; blocks *= 2) {
       wc[nw++] = Tile{base, blocks, 0};
       if (!stem && d.k > 128 && d.k <= 144) wc[nw++] = Tile{9, blocks, 1};
       for (int mt = 2; mt <= 5; ++mt)
         if (mt != base && cdiv(d.k, 32 * mt) * 32 * mt <= cdiv(d.k, 32 * base) * 32 * base + 16 && nw < 15) wc[nw++] = Tile{mt, blocks, 0};
+    }
+    if (allow_split2 && !stem && d.k >= 96) {      // igemm_k2s: 128- / 144-row tiles, whichever pads the rows less
+      const int smt = (cdiv(d.k, 144) * 144 - d.k < cdiv(d.k, 128) * 128 - d.k) ? 9 : 8;
+      for (int blocks = 4; blocks <= 16; blocks *= 2) wc[nw++] = Tile{smt, blocks, 0, 0, 1};
     }
     hipStream_t s2 = as_stream(stream);
     hipEvent_t a0, a1;

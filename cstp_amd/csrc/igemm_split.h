@@ -523,4 +523,246 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K2S  igemm_k2s<MT>:  weight gradient  dwp[m][j] += sum_{n in split} dY[m][n] * Xcol[j][n]   on the split path.
+// BOTH operands are fp32 activations whose memory-contiguous axis (positions n) is the REDUCTION axis, while the MFMA
+// wants 8 consecutive k per lane.  Producer threads therefore stay position-major -- thread (n, slot) gathers 16 rows m
+// of dY and 16 channels of one filter tap of x at its position (coalesced along n, one position decode per tile) --
+// split them and stage LDS images [k = n][column] of 8-byte pieces (4 consecutive columns of one k-row), and the consumers
+// read the k-contiguous MFMA fragments with the hardware-transposing ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group
+// supplies row q / columns 4p..4p+3, lane i receives column i of the 4 rows).
+// Images per plane: main = 32 k-rows x 32 pieces (128 columns), piece c4 of row r at c4 ^ 4*((r&3)|((r>>3&1)<<2)) ^ 2*(r>>2&1):
+// the 32 pieces one half-wave transposed read touches (rows r0..r0+3 and r0+8..r0+11) cover all 64 banks once, and the
+// 16-byte halves the 8 lanes of a ds_write_b128 group write are distinct; MT == 9 adds a 32 x 4-piece image for rows 128..143
+// with its k-rows permuted so that the same 8 rows are contiguous.  Rows m >= M, channels >= Cs and taps beyond the filter
+// are CLAMPED (finite garbage whose products land in outputs nobody reads); positions outside the split / the tensor are
+// out-of-range buffer offsets = zeros.  Tile (16*MT) x 128 outputs, K-tile 32 positions, split-K with f32 atomics as K2.
+template <int MT>
+__global__ void __launch_bounds__(512)
+igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
+          int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
+  static_assert(MT == 8 || MT == 9, "row tiles: 128 main rows (+16)");
+  constexpr int BM = 16 * MT, BJ = 128;
+  constexpr bool XTRA = MT == 9;
+  __shared__ uint2 Am[2][3][32 * 32];
+  __shared__ uint2 Bm[2][3][32 * 32];
+  __shared__ uint2 Ax[XTRA ? 2 : 1][3][32 * 4];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // XCD-aware order as igemm_k2: the ntj column tiles reading one dY panel sit on consecutive slots of one XCD
+  const int xcd = blockIdx.x & 7, slot_b = blockIdx.x >> 3;
+  const int jt = slot_b % ntj;
+  const int panel = (slot_b / ntj) * 8 + xcd;
+  if (panel >= ntm * nsplit) return;
+  const int mtile = panel % ntm, split = panel / ntm;
+  const int m0 = mtile * BM, j0 = jt * BJ;
+  const int S = g.Dp * g.Hp * g.Wp;
+  const int npos = g.Nb * S;
+  const int kt_begin = split * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  if (kt_end > ktiles_total) kt_end = ktiles_total;
+  if (kt_begin >= kt_end) return;
+  const int ntiles = kt_end - kt_begin;
+  const int n_end = kt_end * 32 < npos ? kt_end * 32 : npos;
+
+  auto pc = [](int r, int c4) __attribute__((always_inline)) -> int {
+    return c4 ^ (4 * ((r & 3) | (((r >> 3) & 1) << 2))) ^ (2 * ((r >> 2) & 1));
+  };
+  auto prow = [](int r) __attribute__((always_inline)) -> int {
+    return (r & 3) | (((r >> 3) & 1) << 2) | (((r >> 2) & 1) << 3) | (r & 16);
+  };
+
+  if (wave >= 4) {
+    // ================================================= producers =================================================
+    const int tp_ = t - 256;
+    const int r = tp_ & 31, q = tp_ >> 5;            // k-row (position inside the tile), slot 0..7
+    const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+    const int HWo = g.Hp * g.Wp;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_dy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)((size_t)g.Nb * g.M * S * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)g.Nb * g.Cs * DHWs * 4), 0x00020000);
+    // loop-invariant per-thread offsets: my 16 (+2) dY rows and my 16 channels of my tap
+    unsigned moff[16], mxoff[2], coff[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int m = m0 + 16 * q + j;
+      m = m < g.M ? m : g.M - 1;
+      moff[j] = (unsigned)m * (unsigned)S * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = m0 + 128 + 2 * q + j;
+      m = m < g.M ? m : g.M - 1;
+      mxoff[j] = (unsigned)m * (unsigned)S * 4u;
+    }
+    const int khw = g.kh * g.kw, ntaps = g.kt * khw;
+    int tap, c0;
+    {
+      const int jg = j0 + 16 * q;
+      tap = jg / g.Cp;
+      c0 = jg - tap * g.Cp;
+      if (tap >= ntaps) tap = ntaps - 1;
+    }
+    const int dt = tap / khw, rr_ = tap - dt * khw, dh = rr_ / g.kw, dw = rr_ - dh * g.kw;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int c = c0 + j;
+      c = c < g.Cs ? c : g.Cs - 1;
+      coff[j] = (unsigned)c * (unsigned)DHWs * 4u;
+    }
+    // LDS slots (uint2 index inside one plane) of my stores
+    const int a_slot = r * 32 + pc(r, 4 * q);        // 4 pieces = 32 contiguous bytes (the swizzle permutes whole 32-B
+    const int a_half = (r >> 2) & 1;                 //   segments and swaps their 16-byte halves)
+    const int x_slot = prow(r) * 4 + (q >> 1);       // extra image: piece q>>1, dword q&1
+
+    float ra0[16], rb0[16], rx0[2], ra1[16], rb1[16], rx1[2];
+
+    auto issue_loads = [&](int i, float (&ra)[16], float (&rb)[16], float (&rx)[2]) __attribute__((always_inline)) {
+      const int n = (kt_begin + i) * 32 + r;
+      const bool valid = n < n_end;
+      const int nn = valid ? n : 0;
+      const int b = nn / S, sp = nn - b * S;
+      const int d = sp / HWo, rem = sp - d * HWo;
+      const int h = rem / g.Wp, w = rem - h * g.Wp;
+      const unsigned base_dy = valid ? ((unsigned)b * (unsigned)g.M * (unsigned)S + (unsigned)sp) * 4u : OOB;
+      const int id = d * g.st - g.pt + dt, ih = h * g.sh - g.ph + dh, iw = w * g.sw - g.pw + dw;
+      const bool okx = valid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+      const unsigned base_x = okx ? ((unsigned)b * (unsigned)g.Cs * (unsigned)DHWs + (unsigned)(id * HWs + ih * g.Ws + iw)) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, base_dy + moff[j], 0, 0));
+      if (XTRA) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          rx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, base_dy + mxoff[j], 0, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, base_x + coff[j], 0, 0));
+    };
+
+    auto store16 = [&](uint2* img0, uint2* img1, uint2* img2, int slot, const float (&v)[16]) __attribute__((always_inline)) {
+      // 16 columns = 4 pieces per plane; the two 16-byte halves swap with the row's bit 2
+      uint4 ph[2], pm[2], pl[2];
+      unsigned hh, mm, ll;
+#define CSTP_SPLIT(J, DST, F) split2(v[J], v[(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
+      CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
+      CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
+#undef CSTP_SPLIT
+      uint4* d0 = reinterpret_cast<uint4*>(img0 + (slot & ~3));
+      uint4* d1 = reinterpret_cast<uint4*>(img1 + (slot & ~3));
+      uint4* d2 = reinterpret_cast<uint4*>(img2 + (slot & ~3));
+      d0[a_half] = ph[0]; d0[a_half ^ 1] = ph[1];
+      d1[a_half] = pm[0]; d1[a_half ^ 1] = pm[1];
+      d2[a_half] = pl[0]; d2[a_half ^ 1] = pl[1];
+    };
+    auto split_store = [&](int buf, const float (&ra)[16], const float (&rb)[16], const float (&rx)[2]) __attribute__((always_inline)) {
+      store16(Am[buf][0], Am[buf][1], Am[buf][2], a_slot, ra);
+      store16(Bm[buf][0], Bm[buf][1], Bm[buf][2], a_slot, rb);
+      if (XTRA) {
+        unsigned hh, mm, ll;
+        split2(rx[0], rx[1], hh, mm, ll);
+        reinterpret_cast<unsigned*>(&Ax[buf][0][x_slot])[q & 1] = hh;
+        reinterpret_cast<unsigned*>(&Ax[buf][1][x_slot])[q & 1] = mm;
+        reinterpret_cast<unsigned*>(&Ax[buf][2][x_slot])[q & 1] = ll;
+      }
+    };
+
+    // No load is conditional (tiles past the end of the split read zeros through OOB offsets): the compiler's counted
+    // s_waitcnt keeps two K-tiles in flight (see igemm_k1s).
+    issue_loads(0, ra0, rb0, rx0);
+    issue_loads(1, ra1, rb1, rx1);
+    split_store(0, ra0, rb0, rx0);
+    issue_loads(2, ra0, rb0, rx0);
+    __syncthreads();
+    for (int i = 0; i < ntiles; i += 2) {
+      split_store(1, ra1, rb1, rx1);                  // tile i+1
+      issue_loads(i + 3, ra1, rb1, rx1);
+      __syncthreads();
+      if (i + 1 >= ntiles) break;
+      split_store(0, ra0, rb0, rx0);                  // tile i+2
+      issue_loads(i + 4, ra0, rb0, rx0);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ================================================== consumers ==================================================
+  const int wn = wave;                                // owns column tiles 2*wn, 2*wn+1 (j) of all MT row tiles (m)
+  const int grp = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { acc[i][0][rr] = 0.f; acc[i][1][rr] = 0.f; }
+  // transposed-read slots: rows 8*grp + lq (+4), piece ct*4 + lp of column tile ct
+  const int r_lo = 8 * grp + lq, r_hi = r_lo + 4;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto tr_frag = [&](const uint2* img, int ct) __attribute__((always_inline)) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_lo * 32 + pc(r_lo, ct * 4 + lp)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_hi * 32 + pc(r_hi, ct * 4 + lp)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto tr_frag_x = [&](const uint2* img) __attribute__((always_inline)) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_lo) * 4 + lp));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_hi) * 4 + lp));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  __syncthreads();
+  int buf = 0;
+  for (int i = 0; i < ntiles; ++i) {
+    bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bh[c] = tr_frag(Bm[buf][0], 2 * wn + c);
+      bm[c] = tr_frag(Bm[buf][1], 2 * wn + c);
+      bl[c] = tr_frag(Bm[buf][2], 2 * wn + c);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      bf16x8 ah, am, al;
+      if (XTRA && mt == 8) {
+        ah = tr_frag_x(Ax[XTRA ? buf : 0][0]); am = tr_frag_x(Ax[XTRA ? buf : 0][1]); al = tr_frag_x(Ax[XTRA ? buf : 0][2]);
+      } else {
+        ah = tr_frag(Am[buf][0], mt); am = tr_frag(Am[buf][1], mt); al = tr_frag(Am[buf][2], mt);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x4 a = acc[mt][c];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a, 0, 0, 0);
+        acc[mt][c] = a;
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // C layout: col (j) = lane & 15, row (m) = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = j0 + (2 * wn + c) * 16 + li;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = m0 + mt * 16 + grp * 4 + rr;
+        if (m < g.M && j < Jtot) atomicAdd(&dwp[(size_t)m * Jp + j], acc[mt][c][rr]);
+      }
+    }
+}
+
 }  // namespace cstp
