@@ -832,13 +832,13 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
     static const char* wov = getenv("CSTP_WTILE");
     if (!have_wt && wov != nullptr && wov[0] == 's') {
       int mt = 0, bl = 8;
-      if (sscanf(wov + 1, "%d,%d", &mt, &bl) >= 1 && (mt == 8 || mt == 9)) { wt = Tile{mt, bl, 0, 0, 1}; have_wt = true; }
+      if (sscanf(wov + 1, "%d,%d", &mt, &bl) >= 1 && (mt == 4 || mt == 8 || mt == 9)) { wt = Tile{mt, bl, 0, 0, 1}; have_wt = true; }
     }
     if (have_wt) {
       p.w_mt = wt.m16 ? 9 : wt.mt;
       p.w_blocks = 256 * wt.wm;
       // igemm_k2s (3xbf16 split): 128- or 144-row tiles, 31-bit buffer offsets
-      p.w_split = wt.sp && !p.w_straddle && x_small && y_small && (wt.mt == 8 || wt.mt == 9);
+      p.w_split = wt.sp && !p.w_straddle && x_small && y_small && (wt.mt == 4 || wt.mt == 8 || wt.mt == 9);
       if (wt.sp && !p.w_split) p.w_mt = pick_mt(d.k);
     }
   }
@@ -1074,6 +1074,8 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   if (w_split) {
     if (p.w_mt == 9)
       hipLaunchKernelGGL((igemm_k2s<9>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+    else if (p.w_mt == 4)
+      hipLaunchKernelGGL((igemm_k2s<4>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
     else
       hipLaunchKernelGGL((igemm_k2s<8>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
   } else if (p.w_straddle) {
@@ -1127,8 +1129,10 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
       for (int mt = 2; mt <= 5; ++mt)
         if (mt != base && cdiv(d.k, 32 * mt) * 32 * mt <= cdiv(d.k, 32 * base) * 32 * base + 16 && nw < 15) wc[nw++] = Tile{mt, blocks, 0};
     }
-    if (allow_split2 && !stem && d.k >= 96) {      // igemm_k2s: 128- / 144-row tiles, whichever pads the rows less
-      const int smt = (cdiv(d.k, 144) * 144 - d.k < cdiv(d.k, 128) * 128 - d.k) ? 9 : 8;
+    if (allow_split2 && !stem && d.k >= 48) {      // igemm_k2s: 64- / 128- / 144-row tiles, whichever pads the rows least
+      int smt = 4, pad = cdiv(d.k, 64) * 64 - d.k;
+      if (cdiv(d.k, 128) * 128 - d.k <= pad) { smt = 8; pad = cdiv(d.k, 128) * 128 - d.k; }
+      if (cdiv(d.k, 144) * 144 - d.k < pad) smt = 9;
       for (int blocks = 4; blocks <= 16; blocks *= 2) wc[nw++] = Tile{smt, blocks, 0, 0, 1};
     }
     hipStream_t s2 = as_stream(stream);

@@ -316,7 +316,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // one younger tile (NLOADS loads) is outstanding when a set is consumed and emits counted waits; with a load under
     // `if` it must assume the younger loads may not exist and waits for everything, exposing the memory latency.
     int i = 0;
-#if CSTP_DIAG == 2
+#if CSTP_DIAG == 2 || CSTP_DIAG == 3
     __syncthreads();
     for (; i < ntiles; ++i) __syncthreads();
     return;
@@ -449,11 +449,48 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 
 #else
   __syncthreads();
+#if CSTP_DIAG == 3
+  {   // MFMA + barrier only: all fragments read once
+    const uint4* Bb = &Bs[0][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
+    const uint4* Ab = &As[0][fr * SPL_ROW + (fk ^ spl_swz(fr))];
+    bf16x8 fa[MT][3], fb[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[c][p] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4 * p]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[mt][p] = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4 * p]);
+    for (int i = 0; i < ntiles; ++i) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x4 a = acc[mt][c];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][2], fb[c][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][1], fb[c][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][1], fb[c][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][0], a, 0, 0, 0);
+          acc[mt][c] = a;
+        }
+      __syncthreads();
+    }
+  }
+#else
   {
     int buf = 0;
     for (int i = 0; i < ntiles; ++i) {
+#if CSTP_DIAG == 3
+      const int bsel = 0;                             // every tile re-reads buffer 0 at a loop-invariant address: hoistable
+      const uint4* Bb = &Bs[bsel][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
+      const uint4* Ab = &As[bsel][fr * SPL_ROW + (fk ^ spl_swz(fr))];
+#else
       const uint4* Bb = &Bs[buf][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
       const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
+#endif
       bf16x8 bh[2], bm[2], bl[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -466,22 +503,29 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
         const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
         const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f32x4 a = acc[mt][c];
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a, 0, 0, 0);
-          acc[mt][c] = a;
+        {   // the two column tiles' accumulation chains interleaved (no MFMA depends on its predecessor)
+          f32x4 a0 = acc[mt][0], a1 = acc[mt][1];
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], a1, 0, 0, 0);
+          acc[mt][0] = a0;
+          acc[mt][1] = a1;
         }
       }
       __syncthreads();
       buf ^= 1;
     }
   }
+#endif
 #endif
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg, two column tiles per wave; lane groups q and q^1
@@ -541,10 +585,12 @@ template <int MT>
 __global__ void __launch_bounds__(512)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
           int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
-  static_assert(MT == 8 || MT == 9, "row tiles: 128 main rows (+16)");
+  static_assert(MT == 4 || MT == 8 || MT == 9, "row tiles: 64 or 128 main rows (+16)");
   constexpr int BM = 16 * MT, BJ = 128;
   constexpr bool XTRA = MT == 9;
-  __shared__ uint2 Am[2][3][32 * 32];
+  constexpr int AP = MT == 4 ? 16 : 32;              // 8-byte pieces per k-row of the dY image (64 / 128 columns)
+  constexpr int AR = AP / 2;                         // dY rows per producer slot (8 / 16)
+  __shared__ uint2 Am[2][3][32 * AP];
   __shared__ uint2 Bm[2][3][32 * 32];
   __shared__ uint2 Ax[XTRA ? 2 : 1][3][32 * 4];
 
@@ -569,6 +615,10 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
   auto pc = [](int r, int c4) __attribute__((always_inline)) -> int {
     return c4 ^ (4 * ((r & 3) | (((r >> 3) & 1) << 2))) ^ (2 * ((r >> 2) & 1));
   };
+  // 16-piece rows (MT == 4): reads conflict-free, the 16-byte stores 2-way
+  auto pca = [&](int r, int c4) __attribute__((always_inline)) -> int {
+    return AP == 32 ? pc(r, c4) : (c4 ^ (4 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1))) ^ (2 * ((r >> 2) & 1)));
+  };
   auto prow = [](int r) __attribute__((always_inline)) -> int {
     return (r & 3) | (((r >> 3) & 1) << 2) | (((r >> 2) & 1) << 3) | (r & 16);
   };
@@ -585,10 +635,10 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)g.Nb * g.Cs * DHWs * 4), 0x00020000);
     // loop-invariant per-thread offsets: my 16 (+2) dY rows and my 16 channels of my tap
-    unsigned moff[16], mxoff[2], coff[16];
+    unsigned moff[AR], mxoff[2], coff[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int m = m0 + 16 * q + j;
+    for (int j = 0; j < AR; ++j) {
+      int m = m0 + AR * q + j;
       m = m < g.M ? m : g.M - 1;
       moff[j] = (unsigned)m * (unsigned)S * 4u;
     }
@@ -616,11 +666,12 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
     // LDS slots (uint2 index inside one plane) of my stores
     const int a_slot = r * 32 + pc(r, 4 * q);        // 4 pieces = 32 contiguous bytes (the swizzle permutes whole 32-B
     const int a_half = (r >> 2) & 1;                 //   segments and swaps their 16-byte halves)
+    const int a8_slot = r * AP + pca(r, 2 * q);      // MT == 4: my 8 dY rows = 2 pieces = one aligned 16-byte chunk
     const int x_slot = prow(r) * 4 + (q >> 1);       // extra image: piece q>>1, dword q&1
 
-    float ra0[16], rb0[16], rx0[2], ra1[16], rb1[16], rx1[2];
+    float ra0[AR], rb0[16], rx0[2], ra1[AR], rb1[16], rx1[2];
 
-    auto issue_loads = [&](int i, float (&ra)[16], float (&rb)[16], float (&rx)[2]) __attribute__((always_inline)) {
+    auto issue_loads = [&](int i, float (&ra)[AR], float (&rb)[16], float (&rx)[2]) __attribute__((always_inline)) {
       const int n = (kt_begin + i) * 32 + r;
       const bool valid = n < n_end;
       const int nn = valid ? n : 0;
@@ -632,7 +683,7 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       const bool okx = valid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
       const unsigned base_x = okx ? ((unsigned)b * (unsigned)g.Cs * (unsigned)DHWs + (unsigned)(id * HWs + ih * g.Ws + iw)) * 4u : OOB;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
+      for (int j = 0; j < AR; ++j)
         ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, base_dy + moff[j], 0, 0));
       if (XTRA) {
 #pragma unroll
@@ -659,8 +710,20 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       d1[a_half] = pm[0]; d1[a_half ^ 1] = pm[1];
       d2[a_half] = pl[0]; d2[a_half ^ 1] = pl[1];
     };
-    auto split_store = [&](int buf, const float (&ra)[16], const float (&rb)[16], const float (&rx)[2]) __attribute__((always_inline)) {
-      store16(Am[buf][0], Am[buf][1], Am[buf][2], a_slot, ra);
+    auto store8 = [&](uint2* img0, uint2* img1, uint2* img2, int slot, const float* v) __attribute__((always_inline)) {
+      uint4 ph, pm, pl;
+      unsigned hh, mm, ll;
+      split2(v[0], v[1], hh, mm, ll); ph.x = hh; pm.x = mm; pl.x = ll;
+      split2(v[2], v[3], hh, mm, ll); ph.y = hh; pm.y = mm; pl.y = ll;
+      split2(v[4], v[5], hh, mm, ll); ph.z = hh; pm.z = mm; pl.z = ll;
+      split2(v[6], v[7], hh, mm, ll); ph.w = hh; pm.w = mm; pl.w = ll;
+      *reinterpret_cast<uint4*>(img0 + (slot & ~1)) = ph;
+      *reinterpret_cast<uint4*>(img1 + (slot & ~1)) = pm;
+      *reinterpret_cast<uint4*>(img2 + (slot & ~1)) = pl;
+    };
+    auto split_store = [&](int buf, const float (&ra)[AR], const float (&rb)[16], const float (&rx)[2]) __attribute__((always_inline)) {
+      if constexpr (AR == 16) store16(Am[buf][0], Am[buf][1], Am[buf][2], a_slot, reinterpret_cast<const float(&)[16]>(ra));
+      else store8(Am[buf][0], Am[buf][1], Am[buf][2], a8_slot, ra);
       store16(Bm[buf][0], Bm[buf][1], Bm[buf][2], a_slot, rb);
       if (XTRA) {
         unsigned hh, mm, ll;
@@ -709,6 +772,13 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };
+  auto tr_frag_a = [&](const uint2* img, int ct) __attribute__((always_inline)) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_lo * AP + pca(r_lo, ct * 4 + lp)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_hi * AP + pca(r_hi, ct * 4 + lp)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
   auto tr_frag_x = [&](const uint2* img) __attribute__((always_inline)) -> bf16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_lo) * 4 + lp));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_hi) * 4 + lp));
@@ -733,7 +803,7 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       if (XTRA && mt == 8) {
         ah = tr_frag_x(Ax[XTRA ? buf : 0][0]); am = tr_frag_x(Ax[XTRA ? buf : 0][1]); al = tr_frag_x(Ax[XTRA ? buf : 0][2]);
       } else {
-        ah = tr_frag(Am[buf][0], mt); am = tr_frag(Am[buf][1], mt); al = tr_frag(Am[buf][2], mt);
+        ah = tr_frag_a(Am[buf][0], mt); am = tr_frag_a(Am[buf][1], mt); al = tr_frag_a(Am[buf][2], mt);
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
