@@ -23,6 +23,10 @@
 //   bank-conflict free;  consumer wave w owns columns 32w .. 32w+31 (two 16-column tiles) of all MT row tiles.
 #pragma once
 
+#ifndef CSTP_DIAG
+#define CSTP_DIAG 0      // diagnostic builds: 1 = consumers only synchronise (producer-bound time); 2 = producers only synchronise
+#endif
+
 namespace cstp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -50,69 +54,14 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // raw buffer resource (stride 0, bounds-checked against `bytes`): out-of-range loads return 0
-__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  u32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-  r.z = __builtin_amdgcn_readfirstlane(bytes);
-  r.w = 0x00020000u;
-  return r;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-// Loads issued behind the compiler's back (it does not know these are memory operations and inserts no waits):
-// every value they produce MUST pass through wait_loads<> before its first use -- and must not be copied, converted
-// or repacked before that (a v_mov of a register whose load is still in flight reads stale data), so the staging
-// arrays keep exactly the types the asm writes.
-#ifndef CSTP_DIAG
-#define CSTP_DIAG 0      // 1: consumers only synchronise (producer-bound time); 2: producers only synchronise
-#endif
-#ifndef CSTP_CONS_PIPE
-#define CSTP_CONS_PIPE 0   // 1: consumer reads fragments two row tiles ahead with sched_barrier pins -- measured SLOWER
-                           // (1.96 vs 1.82 ms on the S1 layer) than letting hipcc place the reads, kept for reference
-#endif
-#ifndef CSTP_PROD_STEADY
-#define CSTP_PROD_STEADY 1 // producer steady-state loop without conditional loads (counted vmcnt waits)
-#endif
-#ifndef CSTP_ASM_LOADS
-#define CSTP_ASM_LOADS 0
-#endif
-__device__ __forceinline__ void buf_load_x4(u32x4& d, unsigned voff, u32x4 rs, unsigned soff) {
-#if CSTP_ASM_LOADS
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-#else
-  d = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, (int)rs.z, (int)rs.w), voff, soff, 0));
-#endif
+__device__ __forceinline__ void buf_load_x4(u32x4& d, unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  d = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
-__device__ __forceinline__ void buf_load_x1(float& d, unsigned voff, u32x4 rs, unsigned soff) {
-#if CSTP_ASM_LOADS
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-#else
-  d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, (int)rs.z, (int)rs.w), voff, soff, 0));
-#endif
-}
-// s_waitcnt vmcnt(N) that the register set depends on (N = loads issued after the set's own)
-template <int N, int NA>
-__device__ __forceinline__ void wait_loads(u32x4 (&ra)[NA], float (&rb)[16]) {
-  static_assert(NA >= 2 && NA <= 7, "register set size");
-#if !CSTP_ASM_LOADS
-  return;                                            // compiler-visible loads: it inserts the waits itself
-#endif
-  // operands: NA quads + 16 floats, each tied in place ("+v"); unused quad slots alias ra[0] harmlessly via the switch
-#define CSTP_B16 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]), \
-                 "+v"(rb[8]), "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]), "+v"(rb[12]), "+v"(rb[13]), "+v"(rb[14]), "+v"(rb[15])
-  if constexpr (NA == 2)
-    asm volatile("s_waitcnt vmcnt(%18)" : "+v"(ra[0]), "+v"(ra[1]), CSTP_B16 : "n"(N) : "memory");
-  else if constexpr (NA == 3)
-    asm volatile("s_waitcnt vmcnt(%19)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), CSTP_B16 : "n"(N) : "memory");
-  else if constexpr (NA == 4)
-    asm volatile("s_waitcnt vmcnt(%20)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), CSTP_B16 : "n"(N) : "memory");
-  else if constexpr (NA == 5)
-    asm volatile("s_waitcnt vmcnt(%21)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), CSTP_B16 : "n"(N) : "memory");
-  else if constexpr (NA == 6)
-    asm volatile("s_waitcnt vmcnt(%22)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), CSTP_B16 : "n"(N) : "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(%23)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), CSTP_B16 : "n"(N) : "memory");
-#undef CSTP_B16
+__device__ __forceinline__ void buf_load_x1(float& d, unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 
 // weights: native [k_out][c_in][taps] -> split GEMM operand  wps[group = k/16][m (Mp)][plane (3)][k%16]  bf16,
@@ -214,9 +163,8 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // in the scalar offset, the per-thread part is a VGPR that only changes with the filter tap, and a masked element
     // (halo / padding position, missing half-tile) is an out-of-range offset that the hardware answers with 0 -- no
     // address arithmetic and no selects in the loop; the vector ALU only does the bf16 split.
-    // TWO K-tiles of raw operands are in flight per thread.  The loads are issued from inline asm and waited for
-    // with explicit counted s_waitcnt vmcnt(23) (= "all but the younger tile's 23 loads"): the compiler's own
-    // accounting waits for vmcnt(0) here, which exposes the full memory latency every tile.
+    // TWO K-tiles of raw operands are in flight per thread (see the steady-state loop below for how the compiler is
+    // brought to emit counted s_waitcnt for them).
     const int tp_ = t - 256;
     const int col = tp_ & 127, g2 = (wave - 4) >> 1;
     const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
@@ -230,12 +178,11 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     }
     constexpr unsigned OOB = 0x80000000u;            // host guarantees both buffers are < 2 GiB
     const unsigned src_b4 = (unsigned)((size_t)nb * g.Cs * DHWs) * 4u;
-    const u32x4 rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 4));
-    const u32x4 rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * 96));
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 4));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * 96));
     // A half-tile of my group: 16-byte chunk idc = col + 128 j of BM*6, j = 0..A_IT-1 (the last may be partial)
     constexpr int A_IT = (A_CH + 127) / 128;
     static_assert(A_IT <= 7, "A staging holds at most 7 chunks per producer thread");
-    constexpr int NLOADS = A_IT + 16;                // loads per thread and K-tile
     const bool a_last_ok = col + 128 * (A_IT - 1) < A_CH;
     const unsigned va_full = (unsigned)col * 16u;
     const unsigned va_last = a_last_ok ? va_full : OOB;
@@ -316,24 +263,21 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // one younger tile (NLOADS loads) is outstanding when a set is consumed and emits counted waits; with a load under
     // `if` it must assume the younger loads may not exist and waits for everything, exposing the memory latency.
     int i = 0;
-#if CSTP_DIAG == 2 || CSTP_DIAG == 3
+#if CSTP_DIAG == 2
     __syncthreads();
     for (; i < ntiles; ++i) __syncthreads();
     return;
 #endif
-    if (CSTP_PROD_STEADY && ntiles >= 4) {
+    if (ntiles >= 4) {
       issue_loads(ra0, rb0);                          // tile 0
       issue_loads(ra1, rb1);                          // tile 1
-      wait_loads<NLOADS>(ra0, rb0);
       split_store(0, ra0, rb0);
       issue_loads(ra0, rb0);                          // tile 2
       __syncthreads();
       while (i + 4 < ntiles) {
-        wait_loads<NLOADS>(ra1, rb1);
         split_store(1, ra1, rb1);                     // tile i+1
         issue_loads(ra1, rb1);                        // tile i+3
         __syncthreads();
-        wait_loads<NLOADS>(ra0, rb0);
         split_store(0, ra0, rb0);                     // tile i+2
         issue_loads(ra0, rb0);                        // tile i+4
         __syncthreads();
@@ -343,7 +287,6 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       if (ntiles > 0) issue_loads(ra0, rb0);
       if (ntiles > 1) issue_loads(ra1, rb1);
       if (ntiles > 0) {
-        if (ntiles > 1) wait_loads<NLOADS>(ra0, rb0); else wait_loads<0>(ra0, rb0);
         split_store(0, ra0, rb0);
         if (ntiles > 2) issue_loads(ra0, rb0);
       }
@@ -351,14 +294,12 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     }
     for (; i < ntiles; i += 2) {                      // tail (and the whole loop of short reductions)
       if (i + 1 < ntiles) {                           // stage tile i+1 (set 1) while tile i is consumed
-        if (i + 2 < ntiles) wait_loads<NLOADS>(ra1, rb1); else wait_loads<0>(ra1, rb1);
         split_store(1, ra1, rb1);
         if (i + 3 < ntiles) issue_loads(ra1, rb1);
       }
       __syncthreads();
       if (i + 1 >= ntiles) break;
       if (i + 2 < ntiles) {                           // stage tile i+2 (set 0) while tile i+1 is consumed
-        if (i + 3 < ntiles) wait_loads<NLOADS>(ra0, rb0); else wait_loads<0>(ra0, rb0);
         split_store(0, ra0, rb0);
         if (i + 4 < ntiles) issue_loads(ra0, rb0);
       }
@@ -382,115 +323,12 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   for (int i = 0; i < ntiles; ++i) __syncthreads();
   if (ntiles >= 0) return;
 #endif
-#if CSTP_CONS_PIPE
-  // Fragments are read two row tiles AHEAD of the MFMAs that use them, and the next K-tile's first fragments are read
-  // (right after the barrier that publishes it) under the last two row tiles' MFMAs, so the matrix pipe never waits
-  // for an LDS round trip.  sched_barrier pins that order (the scheduler otherwise sinks each read to its use).
-  constexpr int NS = (MT % 3 == 0) ? 3 : 4;          // A fragment sets in rotation; MT % NS == 0 keeps the rotation per tile
-  static_assert(MT % NS == 0 && MT >= 4, "row-tile count must be a multiple of the fragment-set count");
-  bf16x8 Bf[2][2][3];                                 // [set][column tile][plane]
-  bf16x8 Af[NS][3];
-  const int frag = fr * SPL_ROW + (fk ^ spl_swz(fr));
-  auto load_B = [&](int buf, int set) __attribute__((always_inline)) {
-    const uint4* Bb = &Bs[buf][wn * 32 * SPL_ROW + frag];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) Bf[set][c][p] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4 * p]);
-  };
-  auto load_A = [&](int buf, int mt, int set) __attribute__((always_inline)) {
-    const uint4* Ab = &As[buf][mt * 16 * SPL_ROW + frag];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) Af[set][p] = __builtin_bit_cast(bf16x8, Ab[4 * p]);
-  };
-  auto mma_row = [&](int mt, int aset, int bset) __attribute__((always_inline)) {
-    const bf16x8 ah = Af[aset][0], am = Af[aset][1], al = Af[aset][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const bf16x8 bh = Bf[bset][c][0], bm = Bf[bset][c][1], bl = Bf[bset][c][2];
-      f32x4 a = acc[mt][c];
-      // smallest terms first
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a, 0, 0, 0);
-      acc[mt][c] = a;
-    }
-  };
-  // one K-tile: `bcur` holds its B fragments, A sets 0 and 1 its first two row tiles.  The reads for the NEXT tile are
-  // unconditional (after the last tile they fetch stale LDS that nobody uses).
-  auto tile = [&](int buf, int bcur) __attribute__((always_inline)) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (mt + 2 < MT) {
-        load_A(buf, mt + 2, (mt + 2) % NS);
-      } else if (mt + 2 == MT) {
-        __syncthreads();                              // this tile's LDS reads are all issued; the next tile is published
-        load_B(buf ^ 1, bcur ^ 1);
-        load_A(buf ^ 1, 0, 0);
-      } else {
-        load_A(buf ^ 1, 1, 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_row(mt, mt % NS, bcur);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
   __syncthreads();
-  load_B(0, 0);
-  load_A(0, 0, 0);
-  load_A(0, 1, 1);
-  for (int i = 0; i < ntiles; i += 2) {
-    tile(0, 0);
-    if (i + 1 < ntiles) tile(1, 1);
-  }
-
-#else
-  __syncthreads();
-#if CSTP_DIAG == 3
-  {   // MFMA + barrier only: all fragments read once
-    const uint4* Bb = &Bs[0][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
-    const uint4* Ab = &As[0][fr * SPL_ROW + (fk ^ spl_swz(fr))];
-    bf16x8 fa[MT][3], fb[2][3];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) fb[c][p] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4 * p]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) fa[mt][p] = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4 * p]);
-    for (int i = 0; i < ntiles; ++i) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f32x4 a = acc[mt][c];
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][2], fb[c][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][2], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][1], fb[c][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][1], fb[c][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt][0], fb[c][0], a, 0, 0, 0);
-          acc[mt][c] = a;
-        }
-      __syncthreads();
-    }
-  }
-#else
   {
     int buf = 0;
     for (int i = 0; i < ntiles; ++i) {
-#if CSTP_DIAG == 3
-      const int bsel = 0;                             // every tile re-reads buffer 0 at a loop-invariant address: hoistable
-      const uint4* Bb = &Bs[bsel][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
-      const uint4* Ab = &As[bsel][fr * SPL_ROW + (fk ^ spl_swz(fr))];
-#else
       const uint4* Bb = &Bs[buf][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
       const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
-#endif
       bf16x8 bh[2], bm[2], bl[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -525,8 +363,6 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       buf ^= 1;
     }
   }
-#endif
-#endif
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg, two column tiles per wave; lane groups q and q^1
   // swap one register so that 32 consecutive lanes hold 32 consecutive columns of ONE row (whole 128-byte lines)
