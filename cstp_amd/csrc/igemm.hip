@@ -1109,6 +1109,35 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   return 0;
 }
 
+extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, const int32_t* tile4) {
+  CSTP_REQUIRE(desc && tile4, "null argument");
+  CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
+  Tile t{};
+  const int split = tile4[0], mt = tile4[1];
+  if (mode == 2) {
+    const int blocks = tile4[2];
+    CSTP_REQUIRE(blocks >= 1 && blocks <= 64, "split-K block target / 256 out of range");
+    if (split) {
+      CSTP_REQUIRE(mt == 4 || mt == 8 || mt == 9, "split weight-gradient tiles: 4, 8 or 9 row tiles of 16");
+      t = Tile{mt, blocks, 0, 0, 1};
+    } else {
+      CSTP_REQUIRE((mt >= 1 && mt <= 5) || mt == 9, "native weight-gradient tiles: 1..5 row tiles of 32, or 9 (144 rows)");
+      t = Tile{mt, blocks, mt == 9 ? 1 : 0, 0, 0};
+    }
+  } else if (split) {
+    CSTP_REQUIRE(split_mt_ok(mt), "split tiles: 2, 3, 4, 5, 6, 8 or 9 row tiles of 16");
+    t = Tile{mt, 1, 0, 1, 1};
+  } else {
+    const int wm = tile4[2], tpb = tile4[3];
+    CSTP_REQUIRE((wm == 1 && mt >= 1 && mt <= 5) || (wm == 2 && mt >= 1 && mt <= 2) || (wm == 4 && mt == 1), "native tile shape");
+    CSTP_REQUIRE(tpb == 1 || tpb == 2, "K-tiles per barrier: 1 or 2");
+    t = Tile{mt, wm, 0, tpb, 0};
+  }
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tuned[tune_key(*desc, mode)] = t;
+  return 0;
+}
+
 extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src,
                                     const float* w, float* out, void* ws, size_t ws_bytes, int32_t iters) {
   CSTP_REQUIRE(desc && src && w && out && ws, "null argument");

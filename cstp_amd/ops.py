@@ -73,6 +73,16 @@ def _autotune(lib, desc, mode, src, w, out, ws):
                                    ws.data_ptr(), ws.numel(), 2), "cstp_conv3d_autotune")
 
 
+def set_conv_tile(x_shape, w_shape, stride, padding, mode: int, tile) -> None:
+    """Pin the kernel variant of one convolution geometry and direction (cstp_conv3d_set_tile; mode 0 forward,
+    1 backward_data, 2 backward_weight) and keep the autotuner away from it.  For parity tests and A/B timing."""
+    lib = _lib.load()
+    desc = _desc(tuple(x_shape), tuple(w_shape), _triple(stride), _triple(padding))
+    arr = (ctypes.c_int32 * 4)(*[int(v) for v in tile])
+    check(lib.cstp_conv3d_set_tile(ctypes.byref(desc), int(mode), arr), "cstp_conv3d_set_tile")
+    _tuned.add((int(mode),) + tuple(getattr(desc, f) for f, _ in ConvDesc._fields_))
+
+
 def _desc(x_shape, w_shape, stride, padding) -> ConvDesc:
     n, c, d, h, w = x_shape
     k, c2, kt, kh, kw = w_shape

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 7
+#define CSTP_ABI_VERSION 8
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -76,6 +76,15 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
  * arithmetic on the bf16 matrix cores, csrc/igemm_split.h) and 0 for the native f32 MFMA kernel, out[3] = K-tiles per
  * barrier.  Reporting only (bench.py names the kernel and picks the roofline peak with it). */
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
+
+/* Pin the kernel variant of one geometry and direction (what cstp_conv3d_autotune would otherwise decide by timing):
+ * mode 0 forward / 1 backward_data: tile[0] = 1 for the 3xbf16-split kernel (tile[1] = row tiles of 16: 2,3,4,5,6,8,9) or 0
+ * for the native f32 kernel (tile[1] = row tiles of 32: 1..5, tile[2] = waves along rows 1|2|4, tile[3] = K-tiles per barrier
+ * 1|2); mode 2 backward_weight: tile[0] = 1 split (tile[1] = 4|8|9 row tiles of 16) or 0 native (tile[1] = 1..5 row tiles of
+ * 32, or 9 = the 144-row tile), tile[2] = split-K block target / 256 (4, 8, 16).  Inadmissible requests (3-channel stem, > 27
+ * taps, >= 2 GiB tensors for the split kernels) fall back to a native tile at call time.  Used by the parity tests to put every
+ * kernel variant against the fp64 reference regardless of which one is fastest on the machine at hand. */
+int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, const int32_t* tile4);
 
 /* Optional one-off tuning, OUTSIDE graph capture: times the tile shapes of the forward (mode 0: src = x, w = weights,
  * out = y), data-gradient (mode 1: src = dy, w = weights, out = dx) or weight-gradient (mode 2: src = x, w = dy,
