@@ -99,6 +99,39 @@ def conv_out_shape(x_shape, w_shape, stride, padding):
 
 
 # ----------------------------------------------------------------------------------------------
+# weight gradients on a side stream
+# ----------------------------------------------------------------------------------------------
+# DIRECT_WGRAD is switched on by the training steps (cstp_amd.train) when the parameters' .grad tensors are views of the
+# flat gradient arena and nothing hooks their autograd accumulation (the flat all-reduce path, or no DDP at all).
+DIRECT_WGRAD = False
+OVERLAP_WGRAD = os.environ.get("CSTP_OVERLAP_WGRAD", "1") == "1"
+_side_streams = {}
+_join_pending = set()
+
+
+def _side_stream(device: torch.device) -> torch.cuda.Stream:
+    st = _side_streams.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = st
+    return st
+
+
+def _join_side_streams() -> None:
+    """Make the current stream wait for the side-stream weight gradients (end of every backward pass)."""
+    for idx in list(_join_pending):
+        torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(_side_streams[idx])
+    _join_pending.clear()
+
+
+def _queue_join(device: torch.device) -> None:
+    if device.index not in _join_pending:
+        if not _join_pending:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+        _join_pending.add(device.index)
+
+
+# ----------------------------------------------------------------------------------------------
 # convolution / linear
 # ----------------------------------------------------------------------------------------------
 class _Conv3d(torch.autograd.Function):
@@ -134,15 +167,36 @@ class _Conv3d(torch.autograd.Function):
         desc = ctx.desc
         dy = _req(dy, "conv3d grad_output")
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
-        ws = _workspace(x.device, nbytes)
         dx = dw = db = None
+        side_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and OVERLAP_WGRAD and w.grad is not None and x.dim() == 5 \
+            and x.shape[2] * x.shape[3] * x.shape[4] > 1
+        if side_w:
+            # The weight gradient feeds nothing downstream in the backward chain: it runs on a second HIP stream and adds
+            # itself into the parameter's gradient (a view of the flat gradient arena) there, so the matrix-core-bound
+            # weight-gradient kernels execute beside the HBM-bound BatchNorm backward kernels of the main chain.
+            # (AccumulateGrad sees None for this input; the arena is joined before anything reads it, _join_side_streams.)
+            main = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(main)                     # dy is complete
+            with torch.cuda.stream(side):
+                ws_s = _workspace(x.device, nbytes)
+                dws = torch.empty_like(w)
+                if AUTOTUNE:
+                    _autotune(lib, desc, 2, x, dy, dws, ws_s)
+                check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
+                                                      dws.data_ptr(), ws_s.data_ptr(), ws_s.numel()), "cstp_conv3d_backward_weight")
+                w.grad.add_(dws)
+            x.record_stream(side)
+            dy.record_stream(side)
+            _queue_join(x.device)
+        ws = _workspace(x.device, nbytes)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if AUTOTUNE:
                 _autotune(lib, desc, 1, dy, w, dx, ws)
             check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
                                                 ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not side_w:
             dw = torch.empty_like(w)
             if AUTOTUNE:
                 _autotune(lib, desc, 2, x, dy, dw, ws)

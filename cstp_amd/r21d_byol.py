@@ -30,6 +30,8 @@ from . import ops
 LAYER_SIZES = {1: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
 # Fold BN+ReLU into the consumer convolution's gather (ops.bn_relu_conv3d) instead of materialising it.
 FUSE_BN_INTO_CONV = os.environ.get("CSTP_FUSE_BN", "0") == "1"
+# Run the (no-grad) target-network forward on a second HIP stream, concurrently with the online forward.
+OVERLAP_TARGET_FORWARD = os.environ.get("CSTP_OVERLAP_TARGET", "1") == "1"
 
 
 def layer_sizes_for_depth(depth: int) -> Tuple[int, int, int, int]:
@@ -413,6 +415,13 @@ class R21DBYOL(nn.Module):
         self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
         return self._arenas
 
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st
+
     def _update_target_net(self):
         """EMA of the online encoder+projector into the target (r21d_byol.py:331-337)."""
         if self._arenas is not None:
@@ -441,12 +450,29 @@ class R21DBYOL(nn.Module):
             # online_net(x1); online_net(x2) (r21d_byol.py:359-360) with half the launches, one weight
             # pack per layer and twice the grid on the small deep layers.
             x = torch.cat((x1, x2), dim=0)
-            online_feat, online_proj = self.online_net(x, groups=2)
-            online_pred = self.predictor(online_proj, groups=2)
-            with torch.no_grad():
-                self._update_target_net()                      # EMA BEFORE the target forward (:364)
-                _, target_proj = self.target_net(x, groups=2)  # train-mode BN, own running stats (:365-366)
-                target_swapped = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
+            if OVERLAP_TARGET_FORWARD and x.is_cuda:
+                # The target network's forward depends on nothing the online forward produces (the EMA reads the online
+                # PARAMETERS, which no forward modifies), so it runs on a second HIP stream: its HBM-bound BatchNorm kernels
+                # execute beside the other network's matrix-core-bound convolutions instead of alternating with them.
+                main = torch.cuda.current_stream(x.device)
+                side = self._side_stream(x.device)
+                side.wait_stream(main)                         # x (and last step's optimizer update) are complete
+                with torch.cuda.stream(side), torch.no_grad():
+                    self._update_target_net()                  # EMA BEFORE the target forward (:364)
+                    _, target_proj = self.target_net(x, groups=2)
+                    target_swapped = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
+                online_feat, online_proj = self.online_net(x, groups=2)
+                online_pred = self.predictor(online_proj, groups=2)
+                main.wait_stream(side)
+                target_swapped.record_stream(main)
+                x.record_stream(side)
+            else:
+                online_feat, online_proj = self.online_net(x, groups=2)
+                online_pred = self.predictor(online_proj, groups=2)
+                with torch.no_grad():
+                    self._update_target_net()                      # EMA BEFORE the target forward (:364)
+                    _, target_proj = self.target_net(x, groups=2)  # train-mode BN, own running stats (:365-366)
+                    target_swapped = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
             # loss_fn(pred_1, tproj_2) + loss_fn(pred_2, tproj_1)  (:351-355)
             rows = self._loss_fn(online_pred, target_swapped)
             loss = rows[:b] + rows[b:]

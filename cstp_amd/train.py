@@ -66,6 +66,9 @@ class PretrainStep:
         self._inner = model.module if hasattr(model, "module") else model
         arenas = getattr(self._inner, "_arenas", None)
         self._flat_grad = arenas["grad"] if (flat_allreduce and arenas is not None and hasattr(model, "no_sync")) else None
+        # weight gradients may bypass autograd's accumulation (side stream, ops._Conv3d.backward) when the gradients live in
+        # the arena and no DDP reducer hook waits for them
+        ops.DIRECT_WGRAD = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
         sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
@@ -114,6 +117,7 @@ class FineTuneStep:
         arenas = getattr(inner, "_arenas", None)
         self._flat = flat_allreduce and arenas is not None and hasattr(model, "no_sync") and hasattr(optimizer, "_plan")
         self._g = arenas["grad"] if arenas is not None else None
+        ops.DIRECT_WGRAD = arenas is not None and (self._flat or not hasattr(model, "no_sync"))
 
     def __call__(self, inputs, targets):
         sync_ctx = self.model.no_sync() if self._flat else contextlib.nullcontext()
