@@ -15,6 +15,27 @@
 
 namespace cstp {
 
+#ifndef CSTP_BN_NT
+#define CSTP_BN_NT 1       // streaming (non-temporal) vector stores / last-use loads in the apply kernels
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4(float* p, const float4& v) {
+#if CSTP_BN_NT
+  __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 ld4_last(const float* p) {
+#if CSTP_BN_NT
+  const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+
+
 static inline int bn_nsplit(int n, int c) {
   int ns = cdiv(2048, c);
   if (ns > n) ns = n;
@@ -161,14 +182,14 @@ bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
     const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC4) {
-      float4 v = *reinterpret_cast<const float4*>(x + base + e);
+      float4 v = ld4_last(x + base + e);
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
       if (res != nullptr) {
         const float4 r = *reinterpret_cast<const float4*>(res + base + e);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *reinterpret_cast<float4*>(y + base + e) = v;
+      st4(y + base + e, v);
     } else {
       float v = x[base + e] * sc + sh;
       if (res != nullptr) v += res[base + e];
@@ -201,8 +222,8 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
     const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC4) {
-      const float4 v = *reinterpret_cast<const float4*>(x + base + e);
-      float4 g = *reinterpret_cast<const float4*>(dy + base + e);
+      const float4 v = ld4_last(x + base + e);
+      float4 g = ld4_last(dy + base + e);
       if (remask) {
         g.x = (v.x * sc + sh) > 0.f ? g.x : 0.f; g.y = (v.y * sc + sh) > 0.f ? g.y : 0.f;
         g.z = (v.z * sc + sh) > 0.f ? g.z : 0.f; g.w = (v.w * sc + sh) > 0.f ? g.w : 0.f;
@@ -211,13 +232,13 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
-      if (dres != nullptr) *reinterpret_cast<float4*>(dres + base + e) = g;
+      if (dres != nullptr) st4(dres + base + e, g);
       float4 o;
       o.x = k * (g.x - mb - (v.x - mu) * is * mg);
       o.y = k * (g.y - mb - (v.y - mu) * is * mg);
       o.z = k * (g.z - mb - (v.z - mu) * is * mg);
       o.w = k * (g.w - mb - (v.w - mu) * is * mg);
-      *reinterpret_cast<float4*>(dx + base + e) = o;
+      st4(dx + base + e, o);
     } else {
       float g = dy[base + e];
       if (remask) { if (!((x[base + e] * sc + sh) > 0.f)) g = 0.f; }
