@@ -714,8 +714,9 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
 // sp = 1: the 3xbf16-split kernel igemm_k1s (igemm_split.h), tile (16*mt) x 128, 512 threads
 struct Tile { int mt, wm, m16, tpb, sp; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
 static inline int tile_bm(const Tile& t) { return (t.m16 || t.sp) ? 16 * t.mt : 32 * t.mt * t.wm; }
-static inline int tile_bn(const Tile& t) { return t.sp ? 128 : 32 * (4 / t.wm); }
+static inline int tile_bn(const Tile& t) { return t.sp ? (t.wm == 2 ? 256 : 128) : 32 * (4 / t.wm); }   // split: wm = 128-column halves
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
+static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
 
 // K1 tile choice.  Model: blocks are dealt to the 256 CUs in rounds (a CU's resident blocks share its
 // matrix pipes, so time ~ max blocks per CU x work per block); per-block work ~ BM x BN (K is fixed);
@@ -726,7 +727,8 @@ static Tile pick_tile(int M, long npos, int nclass) {
   static const char* ov = getenv("CSTP_TILE");
   if (ov != nullptr) {
     int mt = 0, wm = 0, tpb = 1;
-    if (ov[0] == 's' && sscanf(ov + 1, "%d", &mt) == 1 && split_mt_ok(mt)) return Tile{mt, 1, 0, 1, 1};   // "s9": split kernel
+    if (ov[0] == 's' && sscanf(ov + 1, "%d", &mt) == 1 && split_mt_ok(mt))    // "s9": split kernel; "s9x": 256-column tile
+      return Tile{mt, (strchr(ov, 'x') != nullptr && mt >= 8) ? 2 : 1, 0, 1, 1};
     if (sscanf(ov, "%d,%d,%d", &mt, &wm, &tpb) >= 2 && mt >= 1 &&
         ((wm == 1 && mt <= 5) || (wm == 2 && mt <= 2) || (wm == 4 && mt == 1)))
       return Tile{mt, wm, 0, tpb == 2 ? 2 : 1};
@@ -808,7 +810,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
-  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_mt_ok(p.f_t.mt)))
+  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t)))
     p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
@@ -816,7 +818,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
-  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_mt_ok(p.d_t.mt))) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t))) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -919,17 +921,21 @@ static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const flo
 }
 
 template <bool DGRAD>
-static void launch_k1s(int mt, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src, const float* bias,
-                       float* out, int ntx, int ntm) {
-#define CSTP_K1S(MT_) hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm)
-  switch (mt) {
-    case 2: CSTP_K1S(2); break;
-    case 3: CSTP_K1S(3); break;
-    case 4: CSTP_K1S(4); break;
-    case 5: CSTP_K1S(5); break;
-    case 6: CSTP_K1S(6); break;
-    case 8: CSTP_K1S(8); break;
-    default: CSTP_K1S(9); break;
+static void launch_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src,
+                       const float* bias, float* out, int ntx, int ntm) {
+#define CSTP_K1S(MT_, NH_) hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD, NH_>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm)
+  if (tl.wm == 2) {             // 256-column tiles: only the tall row tiles (registers: 16*MT*4 accumulators per lane)
+    if (tl.mt == 8) CSTP_K1S(8, 2); else CSTP_K1S(9, 2);
+    return;
+  }
+  switch (tl.mt) {
+    case 2: CSTP_K1S(2, 1); break;
+    case 3: CSTP_K1S(3, 1); break;
+    case 4: CSTP_K1S(4, 1); break;
+    case 5: CSTP_K1S(5, 1); break;
+    case 6: CSTP_K1S(6, 1); break;
+    case 8: CSTP_K1S(8, 1); break;
+    default: CSTP_K1S(9, 1); break;
   }
 #undef CSTP_K1S
 }
@@ -973,8 +979,14 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
+  if (p.f_t.sp && in_affine != nullptr && in_affine->scale_shift != nullptr) {
+    // the split kernel has no fused input transform: such a call runs a native tile (and its operand padding)
+    p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
+    if (p.f_t.sp) p.f_t = Tile{2, 1, 0, 1, 0};
+    p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
+  }
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
-  const bool f_split = p.f_t.sp && !p.f_straddle && (in_affine == nullptr || in_affine->scale_shift == nullptr);
+  const bool f_split = p.f_t.sp && !p.f_straddle;
   if (f_split)
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
                        reinterpret_cast<unsigned short*>(ws), d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp, p.f_Kp / 16, 0);
@@ -992,7 +1004,7 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
-  if (f_split) launch_k1s<false>(p.f_t.mt, grid, s, g, reinterpret_cast<const uint4*>(ws), x, bias, y, ntx, ntm);
+  if (f_split) launch_k1s<false>(p.f_t, grid, s, g, reinterpret_cast<const uint4*>(ws), x, bias, y, ntx, ntm);
   else if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   else if (ia.ss) launch_k1<false, false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, ia.ss, ia.npg, ia.relu);
   else launch_k1<false, false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
@@ -1029,7 +1041,7 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   const int d_bm = tile_bm(p.d_t), d_bn = tile_bn(p.d_t);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
-  if (d_split) launch_k1s<true>(p.d_t.mt, grid, s, g, reinterpret_cast<const uint4*>(ws), dy, nullptr, dx, ntx, ntm);
+  if (d_split) launch_k1s<true>(p.d_t, grid, s, g, reinterpret_cast<const uint4*>(ws), dy, nullptr, dx, ntx, ntm);
   else launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
   return 0;
@@ -1126,7 +1138,8 @@ extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, co
     }
   } else if (split) {
     CSTP_REQUIRE(split_mt_ok(mt), "split tiles: 2, 3, 4, 5, 6, 8 or 9 row tiles of 16");
-    t = Tile{mt, 1, 0, 1, 1};
+    CSTP_REQUIRE(tile4[2] == 0 || tile4[2] == 1 || (tile4[2] == 2 && mt >= 8), "split tiles: 128 columns, or 256 with 8 / 9 row tiles");
+    t = Tile{mt, tile4[2] == 2 ? 2 : 1, 0, 1, 1};
   } else {
     const int wm = tile4[2], tpb = tile4[3];
     CSTP_REQUIRE((wm == 1 && mt >= 1 && mt <= 5) || (wm == 2 && mt >= 1 && mt <= 2) || (wm == 4 && mt == 1), "native tile shape");
@@ -1195,7 +1208,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
-  Tile cand[32] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
+  Tile cand[40] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
                    {9, 1, 1, 1}};
   int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
   if (!straddle) {       // the same tiles with two K-tiles per barrier
@@ -1212,7 +1225,10 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     for (int mt : smt) { const int pad = cdiv(M, 16 * mt) * 16 * mt - M; if (pad < best_pad) best_pad = pad; }
     for (int mt : smt) {
       const int pad = cdiv(M, 16 * mt) * 16 * mt - M;
-      if ((pad <= best_pad + M / 8) && ncand < 32) cand[ncand++] = Tile{mt, 1, 0, 1, 1};
+      if ((pad <= best_pad + M / 8) && ncand < 38) {
+        cand[ncand++] = Tile{mt, 1, 0, 1, 1};
+        if (mt >= 8) cand[ncand++] = Tile{mt, 2, 0, 1, 1};      // 256-column tile
+      }
     }
   }
   hipStream_t s = as_stream(stream);

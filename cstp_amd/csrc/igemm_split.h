@@ -97,11 +97,15 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
   }
 }
 
-template <int MT, bool DGRAD>
+// NH = 128-column halves per block tile (1 or 2).  NH = 2 (256 positions per block) halves the weight-operand traffic per
+// FLOP -- every block re-reads the whole packed weight matrix from L2, 6.2 of the 9.8 GB the 64->144 3x3 layer moves into
+// the CUs -- and the LDS fragment reads per MFMA; each producer thread then gathers two positions.
+template <int MT, bool DGRAD, int NH>
 __global__ void __launch_bounds__(512)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
-  constexpr int BM = 16 * MT, BN = 128;
+  constexpr int BM = 16 * MT, BN = 128 * NH;
+  constexpr int NC = 2 * NH;                         // 16-column tiles per consumer wave
   constexpr int A_CH = BM * 6;                      // 16-byte chunks per A half-tile (one 16-k group)
   __shared__ uint4 As[2][BM * SPL_ROW];
   __shared__ uint4 Bs[2][BN * SPL_ROW];
@@ -168,16 +172,20 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     const int tp_ = t - 256;
     const int col = tp_ & 127, g2 = (wave - 4) >> 1;
     const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
-    const bool nvalid = (n0 + col) < npos;
-    int nb, npd, nph, npw;
-    {
-      int n = nvalid ? (n0 + col) : 0;
-      npw = n % Wp; n /= Wp;
-      nph = n % Hp; n /= Hp;
-      npd = n % Dp; nb = n / Dp;
-    }
+    bool nvalid[NH];
+    int npd[NH], nph[NH], npw[NH];
+    unsigned src_b4[NH];
     constexpr unsigned OOB = 0x80000000u;            // host guarantees both buffers are < 2 GiB
-    const unsigned src_b4 = (unsigned)((size_t)nb * g.Cs * DHWs) * 4u;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {                    // my position in each 128-column half
+      nvalid[h] = (n0 + col + 128 * h) < npos;
+      int n = nvalid[h] ? (n0 + col + 128 * h) : 0;
+      npw[h] = n % Wp; n /= Wp;
+      nph[h] = n % Hp; n /= Hp;
+      npd[h] = n % Dp;
+      const int nb = n / Dp;
+      src_b4[h] = (unsigned)((size_t)nb * g.Cs * DHWs) * 4u;
+    }
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 4));
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * 96));
     // A half-tile of my group: 16-byte chunk idc = col + 128 j of BM*6, j = 0..A_IT-1 (the last may be partial)
@@ -202,30 +210,33 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // incrementally (no division in the loop)
     int ord = g2 / gpt, cg = g2 - ord * gpt;
     int e = g2;
-    unsigned vbj[16];                                 // per-thread byte offsets of the 16 channels at the current tap
+    unsigned vbj[NH][16];                             // per-thread byte offsets of the 16 channels at the current tap
     auto set_tap = [&]() __attribute__((always_inline)) {
       const int tp = DGRAD ? __builtin_amdgcn_readfirstlane(vtap[ord < nvt ? ord : 0]) : ord;
       const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
-      int id, ih, iw;
-      if (DGRAD) {
-        const int et = zt + g.pt - dt, eh = zh + g.ph - dh, ew = zw + g.pw - dw;
-        id = npd + et / g.st; ih = nph + eh / g.sh; iw = npw + ew / g.sw;
-      } else {
-        id = npd * g.st - g.pt + dt; ih = nph * g.sh - g.ph + dh; iw = npw * g.sw - g.pw + dw;
-      }
-      const bool ok = nvalid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
-      const unsigned vb = ok ? src_b4 + (unsigned)(id * HWs + ih * g.Ws + iw) * 4u : OOB;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) vbj[j] = vb + ch4 * j;
+      for (int h = 0; h < NH; ++h) {
+        int id, ih, iw;
+        if (DGRAD) {
+          const int et = zt + g.pt - dt, eh = zh + g.ph - dh, ew = zw + g.pw - dw;
+          id = npd[h] + et / g.st; ih = nph[h] + eh / g.sh; iw = npw[h] + ew / g.sw;
+        } else {
+          id = npd[h] * g.st - g.pt + dt; ih = nph[h] * g.sh - g.ph + dh; iw = npw[h] * g.sw - g.pw + dw;
+        }
+        const bool ok = nvalid[h] && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
+        const unsigned vb = ok ? src_b4[h] + (unsigned)(id * HWs + ih * g.Ws + iw) * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vbj[h][j] = vb + ch4 * j;
+      }
       return tp;
     };
     int tap = set_tap();
 
     u32x4 ra0[A_IT], ra1[A_IT];
-    float rb0[16], rb1[16];
+    float rb0[NH][16], rb1[NH][16];
 
     // issue the loads of my current group into the given register set, then advance to my next group
-    auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[16]) __attribute__((always_inline)) {
+    auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
       const bool have = e < ngroups;                  // uniform; a missing group loads zeros (OOB offsets)
       const unsigned sa = (unsigned)(((size_t)(tap * gpt + cg) * g.Mp + m0) * 96);
       const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
@@ -233,7 +244,9 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       for (int j = 0; j < A_IT; ++j) buf_load_x4(ra[j], j == A_IT - 1 ? vlast : vfull, rs_w, sa + 2048u * j);
       const unsigned sb = have ? (unsigned)(cg << 4) * ch4 : OOB;   // scalar part: first channel of the block
 #pragma unroll
-      for (int j = 0; j < 16; ++j) buf_load_x1(rb[j], have ? vbj[j] : OOB, rs_src, have ? sb : 0u);
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) buf_load_x1(rb[h][j], have ? vbj[h][j] : OOB, rs_src, have ? sb : 0u);
       e += 2;
       cg += 2;
       if (cg >= gpt) {                                // uniform: next tap(s)
@@ -242,20 +255,23 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       }
     };
 
-    auto split_store = [&](int buf, u32x4 (&ra)[A_IT], float (&rb)[16]) __attribute__((always_inline)) {
+    auto split_store = [&](int buf, u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < A_IT; ++j)
         if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
-      uint4 ph[2], pm[2], pl[2];
-      unsigned hh, mm, ll;
-#define CSTP_SPLIT(J, DST, F) split2(rb[J], rb[(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
-      CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
-      CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        uint4 ph[2], pm[2], pl[2];
+        unsigned hh, mm, ll;
+#define CSTP_SPLIT(J, DST, F) split2(rb[h][J], rb[h][(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
+        CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
+        CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
 #undef CSTP_SPLIT
-      uint4* brow = &Bs[buf][b_lds];
-      brow[bq0] = ph[0]; brow[bq1] = ph[1];
-      brow[4 + bq0] = pm[0]; brow[4 + bq1] = pm[1];
-      brow[8 + bq0] = pl[0]; brow[8 + bq1] = pl[1];
+        uint4* brow = &Bs[buf][b_lds + 128 * h * SPL_ROW];   // the swizzle only uses row bits 1..2: the same in both halves
+        brow[bq0] = ph[0]; brow[bq1] = ph[1];
+        brow[4 + bq0] = pm[0]; brow[4 + bq1] = pm[1];
+        brow[8 + bq0] = pl[0]; brow[8 + bq1] = pl[1];
+      }
     };
 
     // tile i lives in set (i & 1) and is staged into LDS buffer (i & 1) during the consumption of tile i - 1.
@@ -309,14 +325,16 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   }
 
   // ===================================== consumer waves: LDS -> MFMA -> output =====================================
-  // lane l feeds A[m = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][n = l&15]; wave w owns columns 32w .. 32w+31
+  // lane l feeds A[m = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][n = l&15]; wave w owns columns 32*NH*w .. +32*NH-1
   const int wn = wave;
   const int fr = lane & 15, fk = lane >> 4;
-  f32x4 acc[MT][2];
+  f32x4 acc[MT][NC];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
 
 #if CSTP_DIAG == 1
   __syncthreads();
@@ -327,11 +345,11 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   {
     int buf = 0;
     for (int i = 0; i < ntiles; ++i) {
-      const uint4* Bb = &Bs[buf][(wn * 32 + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
+      const uint4* Bb = &Bs[buf][(wn * 32 * NH + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
       const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
-      bf16x8 bh[2], bm[2], bl[2];
+      bf16x8 bh[NC], bm[NC], bl[NC];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NC; ++c) {
         bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW]);
         bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4]);
         bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 8]);
@@ -341,22 +359,23 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
         const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
         const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
-        {   // the two column tiles' accumulation chains interleaved (no MFMA depends on its predecessor)
-          f32x4 a0 = acc[mt][0], a1 = acc[mt][1];
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], a1, 0, 0, 0);
-          acc[mt][0] = a0;
-          acc[mt][1] = a1;
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {   // smallest terms first; two column tiles' accumulation chains interleaved
+          f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c + 1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c + 1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c + 1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c + 1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c + 1], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c + 1], a1, 0, 0, 0);
+          acc[mt][c] = a0;
+          acc[mt][c + 1] = a1;
         }
       }
       __syncthreads();
@@ -364,41 +383,44 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     }
   }
 
-  // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg, two column tiles per wave; lane groups q and q^1
+  // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg; per pair of column tiles the lane groups q and q^1
   // swap one register so that 32 consecutive lanes hold 32 consecutive columns of ONE row (whole 128-byte lines)
   const int lcol = lane & 31;
-  const int n = n0 + wn * 32 + lcol;
   const int q = lane >> 4;
   const bool odd = (q & 1) != 0;
-  size_t obase = 0, cstride = 0;
-  const bool nok = n < npos;
-  if (nok) {
-    if (DGRAD) {
-      int qq = n;
-      const int pw = qq % Wp; qq /= Wp;
-      const int ph = qq % Hp; qq /= Hp;
-      const int pd = qq % Dp; const int b = qq / Dp;
-      const int HWf = g.Hp * g.Wp;
-      cstride = (size_t)g.Dp * HWf;
-      obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
-    } else {
-      const int S = Dp * Hp * Wp;
-      const int b = n / S, sp = n - b * S;
-      cstride = (size_t)S;
-      obase = (size_t)b * g.M * cstride + sp;
+#pragma unroll
+  for (int pr = 0; pr < NH; ++pr) {
+    const int n = n0 + wn * 32 * NH + pr * 32 + lcol;
+    size_t obase = 0, cstride = 0;
+    const bool nok = n < npos;
+    if (nok) {
+      if (DGRAD) {
+        int qq = n;
+        const int pw = qq % Wp; qq /= Wp;
+        const int ph = qq % Hp; qq /= Hp;
+        const int pd = qq % Dp; const int b = qq / Dp;
+        const int HWf = g.Hp * g.Wp;
+        cstride = (size_t)g.Dp * HWf;
+        obase = (size_t)b * g.M * cstride + (size_t)(zt + g.st * pd) * HWf + (zh + g.sh * ph) * g.Wp + (zw + g.sw * pw);
+      } else {
+        const int S = Dp * Hp * Wp;
+        const int b = n / S, sp = n - b * S;
+        cstride = (size_t)S;
+        obase = (size_t)b * g.M * cstride + sp;
+      }
     }
-  }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
-      const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
-      const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
-      float ve = odd ? recv : v0;
-      float vo = odd ? v1 : recv;
-      if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
-      if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = acc[mt][2 * pr][r], v1 = acc[mt][2 * pr + 1][r];
+        const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
+        const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
+        float ve = odd ? recv : v0;
+        float vo = odd ? v1 : recv;
+        if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
+        if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
+      }
     }
   }
 }

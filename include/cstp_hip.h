@@ -78,7 +78,8 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
 
 /* Pin the kernel variant of one geometry and direction (what cstp_conv3d_autotune would otherwise decide by timing):
- * mode 0 forward / 1 backward_data: tile[0] = 1 for the 3xbf16-split kernel (tile[1] = row tiles of 16: 2,3,4,5,6,8,9) or 0
+ * mode 0 forward / 1 backward_data: tile[0] = 1 for the 3xbf16-split kernel (tile[1] = row tiles of 16: 2,3,4,5,6,8,9;
+ * tile[2] = 2 selects the 256-column tile, available with 8 / 9 row tiles) or 0
  * for the native f32 kernel (tile[1] = row tiles of 32: 1..5, tile[2] = waves along rows 1|2|4, tile[3] = K-tiles per barrier
  * 1|2); mode 2 backward_weight: tile[0] = 1 split (tile[1] = 4|8|9 row tiles of 16) or 0 native (tile[1] = 1..5 row tiles of
  * 32, or 9 = the 144-row tile), tile[2] = split-K block target / 256 (4, 8, 16).  Inadmissible requests (3-channel stem, > 27

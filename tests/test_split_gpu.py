@@ -55,6 +55,12 @@ def test_split_forward_and_data_gradient(name, mt):
     _run(name, {0: (1, mt, 0, 0), 1: (1, mt, 0, 0), 2: (0, 2, 8, 0)})
 
 
+@pytest.mark.parametrize("mt", [8, 9])
+@pytest.mark.parametrize("name", list(GEOMS))
+def test_split_256_column_tile(name, mt):
+    _run(name, {0: (1, mt, 2, 0), 1: (1, mt, 2, 0), 2: (0, 2, 8, 0)})
+
+
 @pytest.mark.parametrize("mt,blocks", [(4, 4), (8, 8), (9, 8), (9, 16)])
 @pytest.mark.parametrize("name", list(GEOMS))
 def test_split_weight_gradient(name, mt, blocks):
