@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(ctypes.Structure):
@@ -56,6 +56,10 @@ SIGNATURES = {
                                        c_size_t]),
     "cstp_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
+    "cstp_maxpool3d_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                         POINTER(c_int32)]),
+    "cstp_maxpool3d_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                          POINTER(c_int32)]),
     "cstp_channel_sum": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t]),
     "cstp_byol_loss_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32]),
     "cstp_byol_loss_backward": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32]),

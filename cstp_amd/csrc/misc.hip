@@ -43,6 +43,69 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
+// ---- MaxPool3d (models/BE/r3d_byol.py:158: kernel 3, stride 2, padding 1; any k/stride/pad here) -------------------
+// forward: y = max over the window (padding = -inf), idx = flat index (d*H + h)*W + w of the FIRST maximum in (d, h, w)
+// scan order (what aten's CPU kernel keeps: it only replaces on `>` or NaN); one thread per output element, lanes along w.
+__global__ void maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ idx, int rows,
+                                     int D, int H, int W, int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh,
+                                     int sw, int pd, int ph, int pw) {
+  const size_t total = (size_t)rows * Do * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int dd = (int)(r % Do); const size_t row = r / Do;
+    const float* xp = x + row * (size_t)D * H * W;
+    float best = -INFINITY;
+    int bi = -1;
+    for (int a = 0; a < kd; ++a) {
+      const int id = dd * sd - pd + a;
+      if ((unsigned)id >= (unsigned)D) continue;
+      for (int b = 0; b < kh; ++b) {
+        const int ih = ho * sh - ph + b;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int c = 0; c < kw; ++c) {
+          const int iw = wo * sw - pw + c;
+          if ((unsigned)iw >= (unsigned)W) continue;
+          const int fi = (id * H + ih) * W + iw;
+          const float v = xp[fi];
+          if (v > best || v != v || bi < 0) { best = v; bi = fi; }
+        }
+      }
+    }
+    y[i] = best;
+    idx[i] = bi;
+  }
+}
+
+// backward as a GATHER (deterministic, no atomics): dx[p] = sum of dy over the (at most ceil(k/s)^3) windows that cover p
+// and whose recorded argmax is p.
+__global__ void maxpool3d_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                     int rows, int D, int H, int W, int Do, int Ho, int Wo, int kd, int kh, int kw, int sd,
+                                     int sh, int sw, int pd, int ph, int pw) {
+  const size_t total = (size_t)rows * D * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D); const size_t row = r / D;
+    const int fi = (d * H + h) * W + w;
+    // output coordinates o with o*s - p <= c <= o*s - p + k - 1
+    const int d_lo = (d + pd - kd + sd) > 0 ? (d + pd - kd + sd) / sd : 0, d_hi = (d + pd) / sd < Do - 1 ? (d + pd) / sd : Do - 1;
+    const int h_lo = (h + ph - kh + sh) > 0 ? (h + ph - kh + sh) / sh : 0, h_hi = (h + ph) / sh < Ho - 1 ? (h + ph) / sh : Ho - 1;
+    const int w_lo = (w + pw - kw + sw) > 0 ? (w + pw - kw + sw) / sw : 0, w_hi = (w + pw) / sw < Wo - 1 ? (w + pw) / sw : Wo - 1;
+    const size_t obase = row * (size_t)Do * Ho * Wo;
+    float acc = 0.f;
+    for (int a = d_lo; a <= d_hi; ++a)
+      for (int b = h_lo; b <= h_hi; ++b)
+        for (int c = w_lo; c <= w_hi; ++c) {
+          const size_t o = obase + ((size_t)a * Ho + b) * Wo + c;
+          if (idx[o] == fi) acc += dy[o];
+        }
+    dx[i] = acc;
+  }
+}
+
 // ---- BYOL loss: 2 - 2 <x/|x|, y/|y|>; one wave per row -------------------------------------------
 __global__ void byol_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ loss, int b,
                                 int f) {
@@ -472,6 +535,40 @@ extern "C" int cstp_adam_step(void* stream, float* p, const float* g, float* exp
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
                      beta1, beta2, eps, weight_decay, decoupled, (float)bc1, (float)sqrt(bc2));
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline bool pool_dims(int D, int H, int W, const int32_t* k, const int32_t* st, const int32_t* pd, int& Do, int& Ho, int& Wo) {
+  if (D <= 0 || H <= 0 || W <= 0) return false;
+  for (int i = 0; i < 3; ++i) if (k[i] <= 0 || st[i] <= 0 || pd[i] < 0 || 2 * pd[i] > k[i]) return false;
+  Do = (D + 2 * pd[0] - k[0]) / st[0] + 1;
+  Ho = (H + 2 * pd[1] - k[1]) / st[1] + 1;
+  Wo = (W + 2 * pd[2] - k[2]) / st[2] + 1;
+  return Do > 0 && Ho > 0 && Wo > 0;
+}
+
+extern "C" int cstp_maxpool3d_forward(void* stream, const float* x, float* y, int32_t* argmax, int32_t rows, int32_t d, int32_t h,
+                                      int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3) {
+  CSTP_REQUIRE(x && y && argmax && kernel3 && stride3 && pad3 && rows > 0, "bad argument");
+  int Do, Ho, Wo;
+  CSTP_REQUIRE(pool_dims(d, h, w, kernel3, stride3, pad3, Do, Ho, Wo), "bad pooling geometry");
+  CSTP_REQUIRE((size_t)d * h * w < (1ull << 31), "plane too large for int32 argmax");
+  const size_t total = (size_t)rows * Do * Ho * Wo;
+  hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3(stream_grid(total) * 8), dim3(256), 0, as_stream(stream), x, y, argmax, rows, d, h, w,
+                     Do, Ho, Wo, kernel3[0], kernel3[1], kernel3[2], stride3[0], stride3[1], stride3[2], pad3[0], pad3[1], pad3[2]);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_maxpool3d_backward(void* stream, const float* dy, const int32_t* argmax, float* dx, int32_t rows, int32_t d,
+                                       int32_t h, int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3) {
+  CSTP_REQUIRE(dy && argmax && dx && kernel3 && stride3 && pad3 && rows > 0, "bad argument");
+  int Do, Ho, Wo;
+  CSTP_REQUIRE(pool_dims(d, h, w, kernel3, stride3, pad3, Do, Ho, Wo), "bad pooling geometry");
+  const size_t total = (size_t)rows * d * h * w;
+  hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3(stream_grid(total) * 8), dim3(256), 0, as_stream(stream), dy, argmax, dx, rows, d, h, w,
+                     Do, Ho, Wo, kernel3[0], kernel3[1], kernel3[2], stride3[0], stride3[1], stride3[2], pad3[0], pad3[1], pad3[2]);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

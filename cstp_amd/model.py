@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from .r21d_byol import R21DBYOL, get_fine_tuning_parameters, layer_sizes_for_depth
+from .r3d_byol import R3DBYOL
 
 PRETRAIN_TASKS = ("r_byol", "loss_com")
 FINETUNE_TASKS = ("ft_fc", "ft_all", "scratch", "test", "resume")
@@ -64,18 +65,24 @@ def _load_checkpoint(path, device):
 
 
 def generate_model(opts):
-    if opts.model_name != "r21d_byol":
-        raise ValueError("Please check the input backbone! (cstp_amd provides model_name=r21d_byol, got %r)"
+    if opts.model_name not in ("r21d_byol", "r3d_byol"):
+        raise ValueError("Please check the input backbone! (cstp_amd provides model_name=r21d_byol | r3d_byol, got %r)"
                          % (opts.model_name,))
     if opts.task not in PRETRAIN_TASKS + FINETUNE_TASKS:
         raise ValueError("task %r: r21d_byol serves %s" % (opts.task, PRETRAIN_TASKS + FINETUNE_TASKS))
     if not torch.cuda.is_available():
         raise RuntimeError("generate_model needs a HIP device: cstp_amd has no CPU execution path")
-    layer_sizes = layer_sizes_for_depth(opts.model_depth)
-    if opts.task in PRETRAIN_TASKS:
-        model = R21DBYOL(pretrain=True, layer_sizes=layer_sizes)
+    if opts.model_name == "r3d_byol":        # models/model.py:65-70: R3DBYOL(pretrain=..., [cls_bn=True,] opts=opts)
+        if opts.task in PRETRAIN_TASKS:
+            model = R3DBYOL(pretrain=True, opts=opts)
+        else:
+            model = R3DBYOL(pretrain=False, cls_bn=True, opts=opts)
     else:
-        model = R21DBYOL(pretrain=False, num_classes=opts.n_classes, cls_bn=True, layer_sizes=layer_sizes)
+        layer_sizes = layer_sizes_for_depth(opts.model_depth)
+        if opts.task in PRETRAIN_TASKS:
+            model = R21DBYOL(pretrain=True, layer_sizes=layer_sizes)
+        else:
+            model = R21DBYOL(pretrain=False, num_classes=opts.n_classes, cls_bn=True, layer_sizes=layer_sizes)
     local_rank = opts.local_rank if getattr(opts, "local_rank", -1) not in (-1, None) else 0
     torch.cuda.set_device(local_rank)
     model.cuda(local_rank)

@@ -168,8 +168,8 @@ class _Conv3d(torch.autograd.Function):
         dy = _req(dy, "conv3d grad_output")
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
         dx = dw = db = None
-        side_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and OVERLAP_WGRAD and w.grad is not None and x.dim() == 5 \
-            and x.shape[2] * x.shape[3] * x.shape[4] > 1
+        side_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and OVERLAP_WGRAD and x.dim() == 5 \
+            and x.shape[2] * x.shape[3] * x.shape[4] > 1 and w.is_leaf and w.grad is not None
         if side_w:
             # The weight gradient feeds nothing downstream in the backward chain: it runs on a second HIP stream and adds
             # itself into the parameter's gradient (a view of the flat gradient arena) there, so the matrix-core-bound
@@ -408,6 +408,45 @@ class _AvgPool(torch.autograd.Function):
         s = dx.numel() // (n * c)
         check(lib.cstp_avgpool_backward(_stream(), dy.data_ptr(), dx.data_ptr(), n * c, s), "cstp_avgpool_backward")
         return dx
+
+
+class _MaxPool3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        lib = _lib.load()
+        x = _req(x, "max_pool3d input")
+        if x.dim() != 5:
+            raise _lib.CstpError("max_pool3d expects [N, C, D, H, W], got %s" % (tuple(x.shape),))
+        n, c, d, h, w = x.shape
+        k = (ctypes.c_int32 * 3)(*kernel)
+        st = (ctypes.c_int32 * 3)(*stride)
+        pd = (ctypes.c_int32 * 3)(*padding)
+        osz = tuple((sz + 2 * padding[i] - kernel[i]) // stride[i] + 1 for i, sz in enumerate((d, h, w)))
+        y = torch.empty((n, c) + osz, dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, c) + osz, dtype=torch.int32, device=x.device)
+        check(lib.cstp_maxpool3d_forward(_stream(), x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, d, h, w, k, st, pd),
+              "cstp_maxpool3d_forward")
+        ctx.save_for_backward(idx)
+        ctx.geom = (tuple(x.shape), tuple(kernel), tuple(stride), tuple(padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        shape, kernel, stride, padding = ctx.geom
+        dy = _req(dy, "max_pool3d grad_output")
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        n, c, d, h, w = shape
+        check(lib.cstp_maxpool3d_backward(_stream(), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n * c, d, h, w,
+                                          (ctypes.c_int32 * 3)(*kernel), (ctypes.c_int32 * 3)(*stride),
+                                          (ctypes.c_int32 * 3)(*padding)), "cstp_maxpool3d_backward")
+        return dx, None, None, None
+
+
+def max_pool3d(x, kernel_size=3, stride=2, padding=1):
+    """nn.MaxPool3d(kernel_size, stride, padding) (models/BE/r3d_byol.py:158)."""
+    return _MaxPool3d.apply(x, _triple(kernel_size), _triple(stride), _triple(padding))
 
 
 def global_avg_pool(x):

@@ -294,38 +294,23 @@ class R2Plus1DNet(nn.Module):
         return x
 
 
-class R21DBYOL(nn.Module):
-    """forward(x1, x2, o_type='loss_com') -> (loss_byol, (pred_spa, pred_tem, pred_pb_1, pred_pb_2,
-    pred_rot_1, pred_rot_2)) exactly as r21d_byol.py:357-382."""
+class ByolBase(nn.Module):
+    """What the BYOL wrappers of both backbones share (R21DBYOL here, R3DBYOL in r3d_byol.py): the Glorot re-initialisation,
+    the flat parameter / gradient / target arenas, the EMA and the regression loss.  Subclasses provide ``online_net``,
+    ``target_net`` (pretrain), ``pretrain`` and ``_head_bn_calls()``."""
 
-    def __init__(self, pretrain=True, momentum=0.996, layer_sizes=(1, 1, 1, 1), **kwargs):
-        super().__init__()
-        self.pretrain = bool(pretrain)
-        self.layer_sizes = tuple(layer_sizes)
-        if pretrain:
-            self.momentum = momentum
-            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
-            self.target_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
-            self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
-            self._set_grad(self.target_net, False)
-            self.overlap_spa = _MLP(1024, 1024, 5)
-            self.overlap_tem = _MLP(1024, 1024, 5)
-            self.pb_cls = _MLP(512, 512, 5)
-            self.rotate_cls = _MLP(512, 512, 5)
-        else:
-            # fine-tune / test model (r21d_byol.py:293-299): encoder without projector + classifier
-            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=False)
-            self.classify = Linear(512, kwargs["num_classes"])
-            self.cls_bn = kwargs["cls_bn"]
-            if self.cls_bn:
-                print("classify_bn is true, Feature norm and Batch norm on final features")
-                self.cls_bn = BatchNorm1d(512)
+    _arenas = None
+
+    def _head_bn_calls(self):
+        """[(module holding BatchNorms outside the two encoders, forward calls per training step)] (pretrain only)."""
+        raise NotImplementedError
+
+    def _glorot_all(self, leaf_types):
         # Glorot-uniform overwrite of every Linear/Conv3d/BatchNorm weight, in modules() order
-        # (r21d_byol.py:301-329) -- BN gamma becomes U(+-sqrt(6/C)), not 1.
+        # (r21d_byol.py:301-329, r3d_byol.py:265-273) -- BN gamma becomes U(+-sqrt(6/C)), not 1.
         for m in self.modules():
-            if isinstance(m, (Linear, Conv3d, BatchNorm1d, BatchNorm3d)):
+            if isinstance(m, leaf_types):
                 self._glorot_uniform(m.weight)
-        self._arenas = None
 
     # -- init helpers (r21d_byol.py:311-329) ---------------------------------------------------
     @staticmethod
@@ -404,8 +389,11 @@ class R21DBYOL(nn.Module):
             if net is not None:
                 mods = [m for m in net.modules() if isinstance(m, _BatchNorm)]
             else:
-                for h in (self.predictor, self.overlap_spa, self.overlap_tem, self.pb_cls, self.rotate_cls):
-                    mods += [m for m in h.modules() if isinstance(m, _BatchNorm)]
+                head_inc = []
+                for h, calls in self._head_bn_calls():
+                    hm = [m for m in h.modules() if isinstance(m, _BatchNorm)]
+                    mods += hm
+                    head_inc += [calls] * len(hm)
             arena = torch.zeros(len(mods), dtype=torch.long, device=dev)
             for i, m in enumerate(mods):
                 arena[i] = m.num_batches_tracked
@@ -414,7 +402,7 @@ class R21DBYOL(nn.Module):
             nbt[name] = arena
         # forward() calls per step: predictor x2, overlap_spa x1, overlap_tem x1, pb_cls x2, rotate_cls x2
         if self.pretrain:
-            nbt["heads_inc"] = torch.tensor([2, 1, 1, 2, 2], dtype=torch.long, device=dev)
+            nbt["heads_inc"] = torch.tensor(head_inc, dtype=torch.long, device=dev)
         self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
         return self._arenas
 
@@ -439,6 +427,40 @@ class R21DBYOL(nn.Module):
 
     def _cal_loss(self, online_feat_1, online_feat_2, target_feat_1, target_feat_2):
         return self._loss_fn(online_feat_1, target_feat_2) + self._loss_fn(online_feat_2, target_feat_1)
+
+
+class R21DBYOL(ByolBase):
+    """forward(x1, x2, o_type='loss_com') -> (loss_byol, (pred_spa, pred_tem, pred_pb_1, pred_pb_2,
+    pred_rot_1, pred_rot_2)) exactly as r21d_byol.py:357-382."""
+
+    def __init__(self, pretrain=True, momentum=0.996, layer_sizes=(1, 1, 1, 1), **kwargs):
+        super().__init__()
+        self.pretrain = bool(pretrain)
+        self.layer_sizes = tuple(layer_sizes)
+        if pretrain:
+            self.momentum = momentum
+            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+            self.target_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=True)
+            self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
+            self._set_grad(self.target_net, False)
+            self.overlap_spa = _MLP(1024, 1024, 5)
+            self.overlap_tem = _MLP(1024, 1024, 5)
+            self.pb_cls = _MLP(512, 512, 5)
+            self.rotate_cls = _MLP(512, 512, 5)
+        else:
+            # fine-tune / test model (r21d_byol.py:293-299): encoder without projector + classifier
+            self.online_net = R2Plus1DNet(layer_sizes=self.layer_sizes, proj_flag=False)
+            self.classify = Linear(512, kwargs["num_classes"])
+            self.cls_bn = kwargs["cls_bn"]
+            if self.cls_bn:
+                print("classify_bn is true, Feature norm and Batch norm on final features")
+                self.cls_bn = BatchNorm1d(512)
+        self._glorot_all((Linear, Conv3d, BatchNorm1d, BatchNorm3d))
+        self._arenas = None
+
+    def _head_bn_calls(self):
+        # forward() calls per step: predictor x2, overlap_spa x1, overlap_tem x1, pb_cls x2, rotate_cls x2
+        return [(self.predictor, 2), (self.overlap_spa, 1), (self.overlap_tem, 1), (self.pb_cls, 2), (self.rotate_cls, 2)]
 
     def forward(self, x1, x2=None, o_type=None):
         if o_type == "loss_com":

@@ -1,0 +1,204 @@
+"""3D-ResNet-BYOL for MI355X -- host-side mirror of /root/reference/models/BE/r3d_byol.py (the backbone swap of
+BASELINE.json configs[4]), BasicBlock depths 10 / 18 / 34.
+
+Mirrors (same class names, attribute names, state-dict keys, argument meaning and error behaviour):
+  conv3x3x3 :45-53, BasicBlock :69-97, ResNet :139-206 (7x7x7 stem stride (1,2,2) -> BN -> ReLU -> MaxPool3d(3, 2, 1) ->
+  layer1..4 -> AdaptiveAvgPool3d(1) -> view(-1, 512)), Predictor :223-234, R3DBYOL :237-433 (o_type 'loss_com' :381-405,
+  'ft_fc' / 'ft_all' / 'test' :420-428, 'scratch' :429-432), resnet10/18/34 :436-455, get_fine_tuning_parameters :18-42.
+Differences from the R(2+1)D wrapper that the reference makes and this file keeps: the encoder has no projector (the
+predictor and the target comparison act on the 512-d features), target_net is a deepcopy of online_net (identical initial
+weights), the pretext heads are plain Linear layers with 4-way playback-rate / rotation outputs, the fine-tune BatchNorm is
+called ``classify_bn``.  The Bottleneck depths (50+) are shape-broken in the reference (r3d_byol.py:204: ``view(-1, 512)`` of
+2048 features quadruples the batch) and are refused here; shortcut type 'A' (:56-66) builds a CPU tensor inside forward and
+is refused too -- 'B' (1x1x1 conv + BN) is the default (opts.py: --sc_type B).
+
+All arithmetic runs in the HIP kernels of libcstp_hip.so through cstp_amd.ops: the 3x3x3 convolutions are the 27-tap case of the
+implicit-GEMM kernels, the stem the 343-tap / 3-channel case, MaxPool3d has its own kernel pair.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .r21d_byol import BatchNorm1d, BatchNorm3d, ByolBase, Conv3d, Linear, Predictor, ReLU, get_fine_tuning_parameters  # noqa: F401
+
+LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+
+
+def conv3x3x3(in_planes, out_planes, stride=1):
+    return Conv3d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class _Downsample(nn.Sequential):
+    """nn.Sequential(Conv3d 1x1x1 stride s, BatchNorm3d): keys ``downsample.0`` / ``downsample.1`` (r3d_byol.py:177-183)."""
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__(Conv3d(inplanes, planes, kernel_size=1, stride=stride, bias=False), BatchNorm3d(planes))
+
+    def forward(self, x, groups=1):
+        return self[1](self[0](x), groups=groups)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3x3(inplanes, planes, stride)
+        self.bn1 = BatchNorm3d(planes)
+        self.relu = ReLU()
+        self.conv2 = conv3x3x3(planes, planes)
+        self.bn2 = BatchNorm3d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x, groups=1):
+        out = self.bn1(self.conv1(x), relu=True, groups=groups)            # relu(bn1(conv1 x))   :84-86
+        out = self.conv2(out)
+        residual = x if self.downsample is None else self.downsample(x, groups)
+        return self.bn2(out, residual=residual, relu=True, groups=groups)  # relu(bn2(.) + residual)  :88-95, one kernel
+
+
+class _Stage(nn.Sequential):
+    def forward(self, x, groups=1):
+        for block in self:
+            x = block(x, groups)
+        return x
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, sample_size=224, sample_duration=16, shortcut_type="B", num_classes=400):
+        super().__init__()
+        if shortcut_type != "B":
+            raise NotImplementedError("shortcut type %r: cstp_amd implements the reference default 'B' (1x1x1 conv + BN); 'A' "
+                                      "allocates a CPU tensor inside forward (r3d_byol.py:56-66)" % (shortcut_type,))
+        self.inplanes = 64
+        self.conv1 = Conv3d(3, 64, kernel_size=7, stride=(1, 2, 2), padding=(3, 3, 3), bias=False)
+        self.bn1 = BatchNorm3d(64)
+        self.relu = ReLU()
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = _Downsample(self.inplanes, planes * block.expansion, stride)
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return _Stage(*layers)
+
+    def forward(self, x, groups=1):
+        """``groups`` > 1: x holds that many independent forward calls back to back along the batch axis (per-call BN
+        statistics); convolutions and pooling are per-sample, so the result equals separate calls."""
+        x = self.bn1(self.conv1(x), relu=True, groups=groups)
+        x = ops.max_pool3d(x, 3, 2, 1)
+        x = self.layer1(x, groups)
+        x = self.layer2(x, groups)
+        x = self.layer3(x, groups)
+        x = self.layer4(x, groups)
+        return ops.global_avg_pool(x)      # AdaptiveAvgPool3d(1) + view(-1, 512)
+
+
+def _resnet(depth, **kwargs):
+    if int(depth) not in LAYERS:
+        raise ValueError("r3d_byol supports the BasicBlock depths %s, got %r (the reference's Bottleneck depths are "
+                         "shape-broken, r3d_byol.py:204)" % (sorted(LAYERS), depth))
+    return ResNet(BasicBlock, LAYERS[int(depth)], **kwargs)
+
+
+def resnet10(**kwargs):
+    return _resnet(10, **kwargs)
+
+
+def resnet18(**kwargs):
+    return _resnet(18, **kwargs)
+
+
+def resnet34(**kwargs):
+    return _resnet(34, **kwargs)
+
+
+class R3DBYOL(ByolBase):
+    """forward(x1, x2, o_type='loss_com') -> (loss_byol, (pred_spa, pred_tem, pred_pb_1, pred_pb_2, pred_rot_1, pred_rot_2))
+    with [B,5], [B,5], [B,4] x4 logits (r3d_byol.py:381-405)."""
+
+    def __init__(self, momentum=0.996, pretrain=True, cls_bn=False, opts=None):
+        super().__init__()
+        self.pretrain = bool(pretrain)
+        kw = dict(sample_size=opts.sample_size, sample_duration=opts.sample_duration, shortcut_type=opts.sc_type,
+                  num_classes=opts.n_classes)
+        if pretrain:
+            self.momentum = momentum
+            self.online_net = _resnet(opts.model_depth, **kw)
+            self.target_net = copy.deepcopy(self.online_net)
+            self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
+            self._set_grad(self.target_net, False)
+            self.overlap_spa = Linear(1024, 5)
+            self.overlap_tem = Linear(1024, 5)
+            self.pb_cls = Linear(512, 4)
+            self.rot_cls = Linear(512, 4)
+        else:
+            self.online_net = _resnet(opts.model_depth, **kw)
+            self.cls_bn = cls_bn
+            if self.cls_bn:
+                self.classify_bn = BatchNorm1d(512)
+            self.classify = Linear(512, opts.n_classes)
+        self._glorot_all((Linear, Conv3d, BatchNorm1d, BatchNorm3d))   # :265-273 (the deep-copied target is re-drawn too)
+        self._arenas = None
+
+    def _head_bn_calls(self):
+        return [(self.predictor, 2)]
+
+    def forward(self, x1, x2=None, o_type="r_byol"):
+        if o_type == "loss_com":
+            if not self.pretrain:
+                raise AttributeError("R3DBYOL(pretrain=False) has no target_net/predictor: o_type='loss_com' needs pretrain=True")
+            if x2 is None or x2.shape != x1.shape:
+                raise ValueError("o_type='loss_com' needs two clips of identical shape")
+            b = x1.shape[0]
+            x = torch.cat((x1, x2), dim=0)     # both views through one launch sequence, per-view BN statistics (groups=2)
+            online_feat = self.online_net(x, groups=2)
+            online_pred = self.predictor(online_feat, groups=2)
+            with torch.no_grad():
+                self._update_target_net()                     # EMA BEFORE the target forward (:388)
+                target_feat = self.target_net(x, groups=2)
+                target_swapped = torch.cat((target_feat[b:], target_feat[:b]), dim=0).detach()
+            rows = self._loss_fn(online_pred, target_swapped)   # loss_fn(pred_1, t_2) + loss_fn(t_1, pred_2)  (:317-321)
+            loss = rows[:b] + rows[b:]
+            f1, f2 = online_feat[:b], online_feat[b:]
+            feat_cat = torch.cat((f1, f2), dim=1)
+            pred_spa = self.overlap_spa(feat_cat)
+            pred_tem = self.overlap_tem(feat_cat)
+            pred_pb = self.pb_cls(online_feat)
+            pred_rot = self.rot_cls(online_feat)
+            if self._arenas is not None:
+                nbt = self._arenas["nbt"]
+                nbt["online"] += 2
+                nbt["target"] += 2
+                nbt["heads"] += nbt["heads_inc"]
+            self.last_projections = (online_feat[:b], online_feat[b:])   # NT-Xent head input (no projector in this wrapper)
+            return loss.mean(), (pred_spa, pred_tem, pred_pb[:b], pred_pb[b:], pred_rot[:b], pred_rot[b:])
+        if o_type == "r_byol":
+            raise NotImplementedError("o_type='r_byol' reads an attribute the reference never sets (self.shuffle_bn, "
+                                      "r3d_byol.py:410); use o_type='loss_com'")
+        if o_type in ["ft_fc", "ft_all", "test", "scratch"]:
+            if self.pretrain:
+                raise AttributeError("R3DBYOL(pretrain=True) has no classify: o_type=%r needs pretrain=False" % o_type)
+            online_feat = self.online_net(x1)
+            if o_type != "scratch" and self.cls_bn:             # :420-428 vs :429-432
+                online_feat = ops.l2_normalize(online_feat)
+                online_feat = self.classify_bn(online_feat)
+            out = self.classify(online_feat)
+            if self.training and self._arenas is not None:
+                self._arenas["nbt"]["all"] += 1
+                if self.cls_bn and o_type == "scratch":
+                    self.classify_bn.num_batches_tracked -= 1    # not called on the scratch branch (:429-432)
+            return out
+        return None     # the reference falls off the end of forward for any other o_type

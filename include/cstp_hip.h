@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 8
+#define CSTP_ABI_VERSION 9
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -137,6 +137,14 @@ int cstp_bn_forward_eval(void* stream, const float* x, const float* residual, fl
 /* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
 int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);
 int cstp_avgpool_backward(void* stream, const float* dy, float* dx, int32_t rows, int32_t s);
+/* nn.MaxPool3d (models/BE/r3d_byol.py:158,197: kernel 3, stride 2, padding 1 after the stem of the 3D-ResNet backbone; any
+ * kernel / stride / padding with 2*pad <= kernel here).  x: [rows = n*c][d][h][w] -> y: [rows][do][ho][wo]; argmax (int32,
+ * same shape as y) records the flat in-plane index of the first maximum in (d, h, w) scan order, as aten's kernel keeps it.
+ * backward gathers: dx[p] = sum of dy over the windows whose argmax is p (deterministic, no atomics). */
+int cstp_maxpool3d_forward(void* stream, const float* x, float* y, int32_t* argmax, int32_t rows, int32_t d, int32_t h,
+                           int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3);
+int cstp_maxpool3d_backward(void* stream, const float* dy, const int32_t* argmax, float* dx, int32_t rows, int32_t d,
+                            int32_t h, int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3);
 /* out[c] = sum over n,s of x[n][c][s]  (bias gradient of nn.Linear). */
 int cstp_channel_sum(void* stream, const float* x, float* out, int32_t n, int32_t c, int32_t s, void* ws,
                      size_t ws_bytes);

@@ -1,0 +1,168 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the 3D-ResNet-BYOL wrapper (BasicBlock depths 10 / 18 / 34).
+
+Functional restatement (flat ``dict`` of tensors keyed like the reference ``state_dict``) executed with stock PyTorch CPU ops;
+pinned against golden vectors captured from the reference itself (``tests/golden/make_golden_r3d.py`` imports
+``/root/reference/models/BE/r3d_byol.py`` in the build container; fixtures ``tests/golden/r3d_*.npz``).  Nothing in
+``cstp_amd`` imports it.
+
+What each function follows (paths relative to /root/reference/models/BE/r3d_byol.py):
+
+* ``encoder_spec`` / ``model_spec``   ResNet.__init__ :139-191, R3DBYOL.__init__ :237-263 (registration order)
+* ``basic_block``                     BasicBlock.forward :81-97
+* ``encoder_forward``                 ResNet.forward :193-206 (7x7x7 stem, MaxPool3d(3, 2, 1), 4 stages, avg-pool, view(-1, 512))
+* ``model_forward``                   R3DBYOL.forward, o_type == 'loss_com' :381-405
+* ``train_step``                      main_byol.py:60-91 with this wrapper's 4-way playback / rotation heads
+* ``ft_forward``                      :420-428 ('ft_fc' / 'ft_all' / 'test'), :429-432 ('scratch')
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import List, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import r21d_byol_oracle as base
+
+LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+
+
+def _block_spec(prefix: str, cin: int, cout: int, downsample: bool):
+    spec = [(prefix + ".conv1.weight", (cout, cin, 3, 3, 3), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn1", cout)
+    spec += [(prefix + ".conv2.weight", (cout, cout, 3, 3, 3), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn2", cout)
+    if downsample:
+        spec += [(prefix + ".downsample.0.weight", (cout, cin, 1, 1, 1), "conv_w")]
+        spec += base._bn_spec(prefix + ".downsample.1", cout)
+    return spec
+
+
+def encoder_spec(prefix: str, layers: Sequence[int]):
+    spec = [(prefix + ".conv1.weight", (64, 3, 7, 7, 7), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn1", 64)
+    cin = 64
+    for li, (cout, n) in enumerate(zip((64, 128, 256, 512), layers)):
+        for bi in range(n):
+            ds = bi == 0 and (li > 0 or cin != cout)
+            spec += _block_spec("%s.layer%d.%d" % (prefix, li + 1, bi), cin, cout, ds)
+            cin = cout
+    return spec
+
+
+def model_spec(layers: Sequence[int]):
+    spec = encoder_spec("online_net", layers) + encoder_spec("target_net", layers)
+    spec += base._mlp_spec("predictor.net", 512, 4096, 512)
+    for name, din, dout in (("overlap_spa", 1024, 5), ("overlap_tem", 1024, 5), ("pb_cls", 512, 4), ("rot_cls", 512, 4)):
+        spec += [(name + ".weight", (dout, din), "lin_w"), (name + ".bias", (dout,), "lin_b")]
+    return spec
+
+
+def ft_spec(layers: Sequence[int], num_classes: int):
+    spec = encoder_spec("online_net", layers)
+    spec += base._bn_spec("classify_bn", 512)
+    spec += [("classify.weight", (num_classes, 512), "lin_w"), ("classify.bias", (num_classes,), "lin_b")]
+    return spec
+
+
+def closed_form_state(spec, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    for key, shape, kind in spec:
+        t = base.closed_form_tensor(key, shape, kind)
+        sd[key] = t if kind == "buf_nbt" else t.to(dtype)
+    return sd
+
+
+def trainable_keys(layers) -> List[str]:
+    return [k for k, _, kind in model_spec(layers) if base.is_param(kind) and not k.startswith("target_net.")]
+
+
+def encoder_param_pairs(layers):
+    on = [k for k, _, kind in encoder_spec("online_net", layers) if base.is_param(kind)]
+    return [(k, "target_net" + k[len("online_net"):]) for k in on]
+
+
+def closed_form_labels(b: int):
+    j = torch.arange(b, dtype=torch.int64)
+    return {"spa": (j * 7 + 3) % 5, "tem": (j * 3 + 1) % 5, "pb": (j * 5 + 2) % 4, "rot1": (j + 1) % 4, "rot2": (j * 3 + 2) % 4}
+
+
+def basic_block(sd, prefix, x, stride, training=True):
+    out = F.conv3d(x, sd[prefix + ".conv1.weight"], None, stride, 1)
+    out = F.relu(base._bn(sd, prefix + ".bn1", out, training))
+    out = F.conv3d(out, sd[prefix + ".conv2.weight"], None, 1, 1)
+    out = base._bn(sd, prefix + ".bn2", out, training)
+    residual = x
+    if (prefix + ".downsample.0.weight") in sd:
+        residual = F.conv3d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
+        residual = base._bn(sd, prefix + ".downsample.1", residual, training)
+    return F.relu(out + residual)
+
+
+def encoder_forward(sd, prefix, x, layers, training=True):
+    x = F.conv3d(x, sd[prefix + ".conv1.weight"], None, (1, 2, 2), (3, 3, 3))
+    x = F.relu(base._bn(sd, prefix + ".bn1", x, training))
+    x = F.max_pool3d(x, 3, 2, 1)
+    for li, n in enumerate(layers):
+        for bi in range(n):
+            x = basic_block(sd, "%s.layer%d.%d" % (prefix, li + 1, bi), x, 2 if (bi == 0 and li > 0) else 1, training)
+    return x.mean(dim=(2, 3, 4)).view(-1, 512)
+
+
+def ema_update(sd, layers, m: float = base.EMA_MOMENTUM):
+    with torch.no_grad():
+        for kq, kk in encoder_param_pairs(layers):
+            sd[kk] = sd[kk] * m + sd[kq].detach() * (1.0 - m)
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def model_forward(sd, x1, x2, layers, training=True):
+    f1 = encoder_forward(sd, "online_net", x1, layers, training)
+    p1 = base.mlp(sd, "predictor.net", f1, training)
+    f2 = encoder_forward(sd, "online_net", x2, layers, training)
+    p2 = base.mlp(sd, "predictor.net", f2, training)
+    with torch.no_grad():
+        ema_update(sd, layers)
+        t1 = encoder_forward(sd, "target_net", x1, layers, training)
+        t2 = encoder_forward(sd, "target_net", x2, layers, training)
+    loss = base.byol_loss(p1, p2, t1.detach(), t2.detach()).mean()
+    fc = torch.cat((f1, f2), dim=1)
+    logits = (_lin(sd, "overlap_spa", fc), _lin(sd, "overlap_tem", fc), _lin(sd, "pb_cls", f1), _lin(sd, "pb_cls", f2),
+              _lin(sd, "rot_cls", f1), _lin(sd, "rot_cls", f2))
+    return loss, logits, {"feat_1": f1, "feat_2": f2, "pred_1": p1, "pred_2": p2, "tfeat_1": t1, "tfeat_2": t2}
+
+
+def train_step(sd, mom, x1, x2, labels, layers, lr, momentum=0.9, weight_decay=0.0, loss_weight=(0.1, 1, 1, 1, 1), clip=True):
+    keys = trainable_keys(layers)
+    for k in keys:
+        sd[k] = sd[k].detach().requires_grad_(True)
+    loss_byol, logits, extras = model_forward(sd, x1, x2, layers, True)
+    total, ce = base.loss_total(loss_byol, logits, labels, loss_weight)
+    grads = torch.autograd.grad(total, [sd[k] for k in keys])
+    gnorm = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads))
+    coef = float(min(1.0, base.CLIP_VALUE / (float(gnorm) + 1e-6))) if clip else 1.0
+    out_grads = {}
+    with torch.no_grad():
+        for k, g in zip(keys, grads):
+            out_grads[k] = g.detach().clone()
+            g = g * coef
+            p = sd[k].detach()
+            if weight_decay != 0:
+                g = g + weight_decay * p
+            mom[k] = mom[k] * momentum + g if k in mom else g.clone()
+            sd[k] = p - lr * mom[k]
+    info = {"loss_byol": loss_byol.detach(), "loss_total": total.detach(), "ce": [c.detach() for c in ce],
+            "logits": [l.detach() for l in logits], "grad_norm": gnorm.detach(), "grads": out_grads}
+    info.update({k: v.detach() for k, v in extras.items()})
+    return info
+
+
+def ft_forward(sd, x, layers, training=True, o_type="ft_all"):
+    feat = encoder_forward(sd, "online_net", x, layers, training)
+    if o_type != "scratch":
+        feat = F.normalize(feat, p=2, dim=1)
+        feat = base._bn(sd, "classify_bn", feat, training)
+    return _lin(sd, "classify", feat)

@@ -1,0 +1,95 @@
+"""Pin the 3D-ResNet-BYOL oracle (oracle/r3d_byol_oracle.py, fp32) and the module mirror's state-dict contract against golden
+vectors captured from the reference run in fp64 (tests/golden/make_golden_r3d.py).  CPU only."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r21d_byol_oracle as orc
+from oracle import r3d_byol_oracle as r3d
+from test_oracle_golden import STATE_TOLS, TOLS, cs_err, rel
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# r3d_34 (36 train-mode BN layers over a batch of 4): gradient checksums of stock fp32 sit 2.2e-2 from the fp64 truth
+GRAD_SCALE = {"r3d_34_small": 2.0}
+OUT_SCALE = {"r3d_34_small": 3.0}
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def checksums(sd, keys):
+    return np.array([[float(sd[k].detach().double().sum()), float(sd[k].detach().double().abs().sum())] for k in keys])
+
+
+@pytest.mark.parametrize("name", ["r3d_10_small", "r3d_18_small", "r3d_34_small"])
+def test_r3d_oracle_matches_reference_golden(name):
+    g = load(name)
+    depth, b, t, hw, steps = [int(v) for v in g["meta"]]
+    layers = r3d.LAYERS[depth]
+    spec = r3d.model_spec(layers)
+    keys = [str(k) for k in g["state_keys"]]
+    pkeys = [str(k) for k in g["param_keys"]]
+    assert [k for k, _, _ in spec] == keys
+    assert [k for k, _, kind in spec if orc.is_param(kind)] == pkeys
+    sd = r3d.closed_form_state(spec, torch.float32)
+    x1, x2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
+    labels = r3d.closed_form_labels(b)
+    mom = {}
+    for s in range(1, steps + 1):
+        tol, gtol = TOLS[s]
+        tol *= OUT_SCALE.get(name, 1.0)
+        gtol *= GRAD_SCALE.get(name, 1.0)
+        pre = "s%d." % s
+        info = r3d.train_step(sd, mom, x1, x2, labels, layers, float(g["lr"]), 0.9, float(g["wd"]), tuple(g["loss_weight"]), True)
+        assert rel(float(info["loss_byol"]), g[pre + "loss_byol"]) < tol
+        assert rel(float(info["loss_total"]), g[pre + "loss_total"]) < tol
+        assert rel([float(c) for c in info["ce"]], g[pre + "ce"]) < tol
+        assert rel(torch.stack(info["logits"][:2]).numpy(), g[pre + "logits_5"]) < tol
+        assert rel(torch.stack(info["logits"][2:]).numpy(), g[pre + "logits_4"]) < tol
+        assert rel(float(info["grad_norm"]), g[pre + "grad_norm"]) < gtol
+        gn = np.array([float(info["grads"][k].norm()) if k in info["grads"] else -1.0 for k in pkeys])
+        assert rel(gn, g[pre + "grad_norms"]) < gtol
+        assert cs_err(checksums(sd, keys), g[pre + "state_cs"]) < STATE_TOLS[s]
+        mcs = np.array([[float(mom[k].double().sum()), float(mom[k].double().abs().sum())] if k in mom else [0.0, 0.0] for k in pkeys])
+        assert cs_err(mcs, g[pre + "mom_cs"]) < gtol
+        if s == 1:
+            for k in ("feat_1", "feat_2", "pred_1", "pred_2", "tfeat_1", "tfeat_2"):
+                assert rel(info[k].numpy(), g["fwd." + k]) < tol, k
+    # fine-tune / test wrapper
+    fsd = r3d.closed_form_state(r3d.ft_spec(layers, 11), torch.float32)
+    assert list(fsd.keys()) == [str(k) for k in g["ft.state_keys"]]
+    with torch.no_grad():
+        assert rel(r3d.ft_forward(fsd, x1, layers, True).numpy(), g["ft.train_logits"]) < 1e-4 * OUT_SCALE.get(name, 1.0)
+        assert rel(r3d.ft_forward(fsd, x2, layers, False).numpy(), g["ft.eval_logits"]) < 2e-3
+
+
+def _opts(depth, k=101):
+    return argparse.Namespace(model_depth=depth, sample_size=56, sample_duration=8, sc_type="B", n_classes=k)
+
+
+def test_r3d_module_state_dict_contract_and_errors():
+    from cstp_amd.r3d_byol import R3DBYOL
+    for depth, name in ((10, "r3d_10_small"), (18, "r3d_18_small"), (34, "r3d_34_small")):
+        g = load(name)
+        m = R3DBYOL(pretrain=True, opts=_opts(depth))
+        assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+        assert [k for k, _ in m.named_parameters()] == [str(k) for k in g["param_keys"]]
+        ft = R3DBYOL(pretrain=False, cls_bn=True, opts=_opts(depth, 11))
+        assert list(ft.state_dict().keys()) == [str(k) for k in g["ft.state_keys"]]
+    m = R3DBYOL(pretrain=True, opts=_opts(10))
+    # the deep-copied target is re-initialised by the Glorot loop: it does not equal the online network (r3d_byol.py:246,265)
+    assert not torch.equal(m.online_net.conv1.weight, m.target_net.conv1.weight)
+    assert all(not p.requires_grad for p in m.target_net.parameters())
+    with pytest.raises(ValueError):
+        R3DBYOL(pretrain=True, opts=_opts(50))
+    o = _opts(18)
+    o.sc_type = "A"
+    with pytest.raises(NotImplementedError):
+        R3DBYOL(pretrain=True, opts=o)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1), torch.zeros(1), o_type="r_byol")
+    assert m(torch.zeros(1), torch.zeros(1), o_type="nonsense") is None
