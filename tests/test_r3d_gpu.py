@@ -140,3 +140,32 @@ def test_r3d_factory_and_pretrain_driver(tmp_path):
     mod.main(opts)
     rows = open(str(tmp_path / "synthetic" / "loss_com" / "synthetic_train_clip8modelr3d_byol10.log")).read().strip().split("\n")
     assert len(rows) == 3 and all(np.isfinite(float(r.split("\t")[1])) for r in rows[1:])
+
+
+def test_r3d_finetune_and_test_drivers(tmp_path, capsys):
+    """main_ft_mp.py --task scratch and test.py with --model_name r3d_byol: train, validate under model.eval(), keep the best
+    checkpoint, load it strictly for the video-level test."""
+    import importlib.util
+    import os
+    from cstp_amd.opts import parse_opts
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("cstp_script_%s_r3d" % name, os.path.join(root, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    common = ["--dataset", "synthetic", "--n_classes", "4", "--batch_size", "8", "--sample_duration", "8", "--sample_size", "56",
+              "--model_name", "r3d_byol", "--model_depth", "10", "--n_workers", "0", "--synthetic_len", "32",
+              "--result_path", str(tmp_path), "--weight_decay", "1e-4"]
+    opts = parse_opts(common + ["--task", "scratch", "--learning_rate", "0.02", "--n_epochs", "3"])
+    opts.highest_val = {"name": 0}
+    load("main_ft_mp").main(opts)
+    d = tmp_path / "synthetic" / "scratch"
+    best = [f for f in os.listdir(d) if f.endswith("_max.pth")]
+    assert len(best) == 1
+    md = torch.load(str(d / best[0]), map_location="cpu")
+    assert md["arch"] == "r3d_byol-10" and "module.classify_bn.running_mean" in md["state_dict"]
+    opts = parse_opts(common + ["--task", "test", "--t_ft_task", "scratch"])
+    acc = load("test").run(opts)
+    assert 0.0 <= acc <= 1.0 and "Video accuracy" in capsys.readouterr().out
