@@ -46,10 +46,14 @@ class ConvTimer:
         self.key = (n, c, d, h, w, k, kh)
         self.pairs, self.enabled = [], False
         self._cur = None
+        self.main_stream = torch.cuda.current_stream().cuda_stream
 
     def match(self, what, desc):
+        # launches on the step's main stream only (= the online network's): a side stream, if the model uses one, overlaps its
+        # kernels with the main stream's, and an event pair around such a launch measures queueing, not the kernel
         return self.enabled and what == "conv3d_forward" and \
-            (desc.n, desc.c, desc.d, desc.h, desc.w, desc.k, desc.kh) == self.key
+            (desc.n, desc.c, desc.d, desc.h, desc.w, desc.k, desc.kh) == self.key and \
+            torch.cuda.current_stream().cuda_stream == self.main_stream
 
     def start(self):
         self._cur = torch.cuda.Event(enable_timing=True)

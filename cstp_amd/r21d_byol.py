@@ -30,11 +30,9 @@ from . import ops
 LAYER_SIZES = {1: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
 # Fold BN+ReLU into the consumer convolution's gather (ops.bn_relu_conv3d) instead of materialising it.
 FUSE_BN_INTO_CONV = os.environ.get("CSTP_FUSE_BN", "0") == "1"
-# Run the (no-grad) target-network forward on a second HIP stream, concurrently with the online forward: -3 % step time on
-# MI355X (99.1 vs 102.2 ms at cfg2).  Opt-in (CSTP_OVERLAP_TARGET=1): with both networks' convolutions in flight at once,
-# HIP events around one launch no longer measure that kernel's own duration, and bench.py's roofline leg (and any per-kernel
-# profile) is quoted on the default, serial forward.
-OVERLAP_TARGET_FORWARD = os.environ.get("CSTP_OVERLAP_TARGET", "0") == "1"
+# Run the (no-grad) target-network forward on a second HIP stream, staggered behind the online network's stem + conv2 stage
+# (R21DBYOL.forward): -2.5 ms/step at cfg2 on MI355X.  CSTP_OVERLAP_TARGET=0 runs the two forwards back to back.
+OVERLAP_TARGET_FORWARD = os.environ.get("CSTP_OVERLAP_TARGET", "1") == "1"
 
 
 def layer_sizes_for_depth(depth: int) -> Tuple[int, int, int, int]:
@@ -280,11 +278,14 @@ class R2Plus1DNet(nn.Module):
         if self.proj_flag:
             self.project = Projector(dim=512, projection_size=512, projection_hidden_size=4096)
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, after_conv2=None):
         """``groups`` > 1: x holds that many independent forward calls back to back along the batch axis
-        (BN statistics stay per call); convolutions are per-sample, so the result equals separate calls."""
+        (BN statistics stay per call); convolutions are per-sample, so the result equals separate calls.
+        ``after_conv2``: called once the conv2 stage is enqueued (R21DBYOL starts the target network's stream there)."""
         x = self.bn1(self.conv1(x, groups), relu=True, groups=groups)
         x = self.conv2(x, groups)
+        if after_conv2 is not None:
+            after_conv2()
         x = self.conv3(x, groups)
         x = self.conv4(x, groups)
         x = self.conv5(x, groups)
@@ -481,14 +482,22 @@ class R21DBYOL(ByolBase):
                 # execute beside the other network's matrix-core-bound convolutions instead of alternating with them.
                 main = torch.cuda.current_stream(x.device)
                 side = self._side_stream(x.device)
-                side.wait_stream(main)                         # x (and last step's optimizer update) are complete
-                with torch.cuda.stream(side), torch.no_grad():
-                    self._update_target_net()                  # EMA BEFORE the target forward (:364)
-                    _, target_proj = self.target_net(x, groups=2)
-                    target_swapped = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
-                online_feat, online_proj = self.online_net(x, groups=2)
+                tgt = {}
+
+                def start_target():
+                    # STAGGERED: the side stream starts once the online network's stem and conv2 stage (the big 56x56 layers,
+                    # where the dominant kernel lives) are through, so those launches run alone -- their HIP-event timing stays
+                    # the kernel's own duration -- and the target forward overlaps the online conv3..conv5 stages and heads.
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side), torch.no_grad():
+                        self._update_target_net()              # EMA BEFORE the target forward (:364)
+                        _, target_proj = self.target_net(x, groups=2)
+                        tgt["swapped"] = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
+
+                online_feat, online_proj = self.online_net(x, groups=2, after_conv2=start_target)
                 online_pred = self.predictor(online_proj, groups=2)
                 main.wait_stream(side)
+                target_swapped = tgt["swapped"]
                 target_swapped.record_stream(main)
                 x.record_stream(side)
             else:
