@@ -23,7 +23,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .r21d_byol import BatchNorm1d, BatchNorm3d, ByolBase, Conv3d, Linear, Predictor, ReLU, get_fine_tuning_parameters  # noqa: F401
+from .r21d_byol import (OVERLAP_TARGET_FORWARD, BatchNorm1d, BatchNorm3d, ByolBase, Conv3d, Linear, Predictor, ReLU,  # noqa: F401
+                        get_fine_tuning_parameters)
 
 LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
 
@@ -94,12 +95,15 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return _Stage(*layers)
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, after_layer1=None):
         """``groups`` > 1: x holds that many independent forward calls back to back along the batch axis (per-call BN
-        statistics); convolutions and pooling are per-sample, so the result equals separate calls."""
+        statistics); convolutions and pooling are per-sample, so the result equals separate calls.
+        ``after_layer1``: called once layer1 is enqueued (R3DBYOL starts the target network's stream there)."""
         x = self.bn1(self.conv1(x), relu=True, groups=groups)
         x = ops.max_pool3d(x, 3, 2, 1)
         x = self.layer1(x, groups)
+        if after_layer1 is not None:
+            after_layer1()
         x = self.layer2(x, groups)
         x = self.layer3(x, groups)
         x = self.layer4(x, groups)
@@ -164,12 +168,32 @@ class R3DBYOL(ByolBase):
                 raise ValueError("o_type='loss_com' needs two clips of identical shape")
             b = x1.shape[0]
             x = torch.cat((x1, x2), dim=0)     # both views through one launch sequence, per-view BN statistics (groups=2)
-            online_feat = self.online_net(x, groups=2)
-            online_pred = self.predictor(online_feat, groups=2)
-            with torch.no_grad():
-                self._update_target_net()                     # EMA BEFORE the target forward (:388)
-                target_feat = self.target_net(x, groups=2)
-                target_swapped = torch.cat((target_feat[b:], target_feat[:b]), dim=0).detach()
+            if OVERLAP_TARGET_FORWARD and x.is_cuda:
+                # target forward on a second HIP stream, staggered behind the online stem + layer1 (see R21DBYOL.forward)
+                main = torch.cuda.current_stream(x.device)
+                side = self._side_stream(x.device)
+                tgt = {}
+
+                def start_target():
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side), torch.no_grad():
+                        self._update_target_net()             # EMA BEFORE the target forward (:388)
+                        target_feat = self.target_net(x, groups=2)
+                        tgt["swapped"] = torch.cat((target_feat[b:], target_feat[:b]), dim=0).detach()
+
+                online_feat = self.online_net(x, groups=2, after_layer1=start_target)
+                online_pred = self.predictor(online_feat, groups=2)
+                main.wait_stream(side)
+                target_swapped = tgt["swapped"]
+                target_swapped.record_stream(main)
+                x.record_stream(side)
+            else:
+                online_feat = self.online_net(x, groups=2)
+                online_pred = self.predictor(online_feat, groups=2)
+                with torch.no_grad():
+                    self._update_target_net()                     # EMA BEFORE the target forward (:388)
+                    target_feat = self.target_net(x, groups=2)
+                    target_swapped = torch.cat((target_feat[b:], target_feat[:b]), dim=0).detach()
             rows = self._loss_fn(online_pred, target_swapped)   # loss_fn(pred_1, t_2) + loss_fn(t_1, pred_2)  (:317-321)
             loss = rows[:b] + rows[b:]
             f1, f2 = online_feat[:b], online_feat[b:]
