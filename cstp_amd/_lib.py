@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(ctypes.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     "cstp_ntxent_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "cstp_ntxent_forward": (c_int32, [_P, _P, _P, c_int32, c_int32, c_float, _P, c_size_t]),
     "cstp_ntxent_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, c_size_t]),
+    "cstp_clip_assemble": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                     c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "cstp_ema_update": (c_int32, [_P, _P, _P, c_size_t, c_double]),
     "cstp_sumsq": (c_int32, [_P, _P, c_size_t, _P, _P, c_size_t]),
     "cstp_clip_coef": (c_int32, [_P, _P, c_float, _P, _P]),

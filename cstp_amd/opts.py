@@ -20,7 +20,7 @@ _FLAGS = [
     # datasets
     ("frame_dir", "dataset/HMDB51/", str, "path of jpg files"),
     ("annotation_path", "dataset/HMDB51_labels", str, "label paths"),
-    ("dataset", "HMDB51", str, "HMDB51 | UCF101 | Kinetics | synthetic"),
+    ("dataset", "HMDB51", str, "HMDB51 | UCF101 | Kinetics | synthetic | synthetic_video"),
     ("split", 1, str, "split id (HMDB51 / UCF101)"),
     ("modality", "RGB", str, "RGB | Flow"),
     ("input_channels", 3, int, "3 | 2"),

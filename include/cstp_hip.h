@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 9
+#define CSTP_ABI_VERSION 10
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -174,6 +174,19 @@ int cstp_ntxent_forward(void* stream, const float* reps, float* loss, int32_t tw
                         void* ws, size_t ws_bytes);
 int cstp_ntxent_backward(void* stream, const float* reps, const float* dloss, float* dreps, int32_t two_n,
                          int32_t f, float temperature, void* ws, size_t ws_bytes);
+
+/* ---- GPU clip assembly (data path next to the step: data_process/datasets.py:876-948, preprocess_data.py:479-581,1103-1110) ----
+ * frames: decoded video, uint8 [f][h][w][3] in HBM.  For each of the t frames frame_idx[i] (device int32): Image.transpose(rot in
+ * {0, 90, 180, 270}, counter-clockwise) -> Image.crop at (box_x0, box_y0) of the ROTATED frame -> Image.resize((size, size),
+ * Image.BICUBIC) -> FLIP_LEFT_RIGHT if flip -> ToTensor -> x*2-1 clamped  =>  out fp32 [3][t][size][size].
+ * The resize is Pillow's fixed-point algorithm bit for bit; its integer coefficient tables come from the caller (kh/kv int32
+ * [size][ks*], bh/bv int32 [size][2] = (first tap, tap count), computed as Resample.c's precompute_coeffs +
+ * normalize_coeffs_8bpc do for the crop's width / height -- cstp_amd/clip_ops.py); the horizontal pass covers the crop rows
+ * [row_first, row_first + rows) that the vertical pass reads and writes them to tmp (uint8 [t][rows][size][3]). */
+int cstp_clip_assemble(void* stream, const uint8_t* frames, int32_t f, int32_t h, int32_t w, const int32_t* frame_idx, int32_t t,
+                       int32_t rot, int32_t box_x0, int32_t box_y0, int32_t size, int32_t flip, const int32_t* kh,
+                       const int32_t* bh, int32_t ksh, const int32_t* kv, const int32_t* bv, int32_t ksv, int32_t row_first,
+                       int32_t rows, uint8_t* tmp, float* out);
 
 /* ---- per-step utilities over FLAT parameter arenas -------------------------------------- */
 /* EMA r21d_byol.py:331-337: target = target*m + online*(1-m) over n floats. */

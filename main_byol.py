@@ -14,8 +14,10 @@ What is kept from /root/reference/main_byol.py: seeding (:144-146), env:// proce
 cosine/warm-up schedule starting at 1e-5 (:252-258,269), the per-step loss composition, clip at 18
 and optimiser step (:60-91), the per-iteration print columns (:96-117), the per-epoch TSV row
 (:119-130) and the save_{epoch}.pth checkpoint dict every 100 epochs (:132-140).
-What differs: --dataset synthetic feeds random clips (the PIL/LMDB pipeline is out of scope);
-scalars are fetched from the device once per printed iteration rather than seven times.
+What differs: --dataset synthetic feeds random clips through a DataLoader; --dataset synthetic_video keeps decoded
+uint8 videos in HBM and samples / rotates / crops / resizes / flips / normalises the clip pairs on the GPU
+(cstp_amd.sampler + cstp_clip_assemble) in place of the reference's PIL worker pipeline; reading JPEG / LMDB data
+sets is out of scope; scalars are fetched from the device once per printed iteration rather than seven times.
 """
 from __future__ import annotations
 
@@ -48,9 +50,13 @@ def reduce_mean(t: torch.Tensor, world_size: int) -> torch.Tensor:
 
 
 def build_dataset(opts):
+    if opts.dataset == "synthetic_video":
+        from cstp_amd.clip_ops import GpuVideoClips
+        return GpuVideoClips(torch.device("cuda", opts.local_rank), sample_duration=opts.sample_duration,
+                             sample_size=opts.sample_size, length=opts.synthetic_len, seed=opts.manual_seed)
     if opts.dataset != "synthetic":
-        raise NotImplementedError("dataset %r: only --dataset synthetic is built in (the reference's PIL/LMDB datasets "
-                                  "are outside this package's scope)" % opts.dataset)
+        raise NotImplementedError("dataset %r: --dataset synthetic and synthetic_video are built in (reading the reference's "
+                                  "JPEG / LMDB data sets is outside this package's scope)" % opts.dataset)
     return SyntheticClips(opts.synthetic_len, opts.sample_duration, opts.sample_size, opts.manual_seed)
 
 
@@ -114,10 +120,15 @@ def main_worker(local_rank, opts):
     train_data = build_dataset(opts)
     print("Length of training data = ", len(train_data))
     per_rank = int(opts.batch_size / opts.world_size)
-    sampler = DistributedSampler(train_data, num_replicas=opts.world_size, rank=max(opts.rank, 0), shuffle=True) \
-        if opts.distributed else None
-    loader = DataLoader(train_data, batch_size=per_rank, shuffle=sampler is None, num_workers=opts.n_workers,
-                        pin_memory=True, sampler=sampler, drop_last=True)
+    if opts.dataset == "synthetic_video":
+        from cstp_amd.clip_ops import GpuClipLoader
+        loader = sampler = GpuClipLoader(train_data, per_rank, rank=max(opts.rank, 0), world_size=opts.world_size,
+                                         seed=opts.manual_seed)
+    else:
+        sampler = DistributedSampler(train_data, num_replicas=opts.world_size, rank=max(opts.rank, 0), shuffle=True) \
+            if opts.distributed else None
+        loader = DataLoader(train_data, batch_size=per_rank, shuffle=sampler is None, num_workers=opts.n_workers,
+                            pin_memory=True, sampler=sampler, drop_last=True)
 
     print("Loading model... ", opts.model_name, opts.model_depth)
     model, parameters = generate_model(opts)

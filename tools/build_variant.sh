@@ -4,5 +4,5 @@ set -e
 name=$1; shift
 mkdir -p build_ab
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -Iinclude -Icstp_amd/csrc "$@" -o build_ab/$name.so \
-  cstp_amd/csrc/igemm.hip cstp_amd/csrc/bn.hip cstp_amd/csrc/misc.hip
+  cstp_amd/csrc/igemm.hip cstp_amd/csrc/bn.hip cstp_amd/csrc/misc.hip cstp_amd/csrc/clip.hip
 echo built build_ab/$name.so
