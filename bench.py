@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: BF16 dense (~2.5 PF)
-SPLIT_PRODUCTS = 6              # bf16 MFMA products per fp32 product in the 3xbf16-split kernels (csrc/igemm_split.h)
+SPLIT_PRODUCTS = {2: 3, 3: 6}   # 16-bit MFMA products per fp32 product: f16 pair / bf16 triple (csrc/igemm_split.h)
 DEPTH, B_LOCAL, T, HW = 18, 16, 16, 112
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 0.0, 0.0)
 NTXENT_WEIGHT = 1.0
@@ -182,26 +182,33 @@ def main():
         tile = (ctypes.c_int32 * 4)()
         d_s1 = _desc((2 * args.batch, 64, T, HW // 2, HW // 2), (144, 64, 1, 3, 3), (1, 1, 1), (0, 1, 1))
         _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(d_s1), 0, tile), "cstp_conv3d_query_tile")
-        split = bool(tile[2])
-        # fp32-equivalent peak of the kernel that ran: native f32 MFMA 157.3 TF/s; the split kernel issues six bf16 MFMA
-        # products per fp32 product, so its ceiling is the bf16 dense peak / 6 (the algorithmic FLOPs stay the fp32 ones)
-        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else F32_MFMA_PEAK_TFLOPS
-        kname = ("igemm_k1s<%d,fwd> (3xbf16-split, %dx%d tile, bf16 MFMA 16x16x32 x6, f32 accumulate)" % (tile[0] // 16, tile[0], tile[1])
+        terms = int(tile[2])                          # 0 native f32 MFMA, 2 = f16 pair, 3 = bf16 triple
+        split = terms != 0
+        products = SPLIT_PRODUCTS.get(terms, 1)
+        # fp32-equivalent peak of the kernel that ran: native f32 MFMA 157.3 TF/s; a split kernel issues 3 (f16 pair) or 6
+        # (bf16 triple) 16-bit MFMA products per fp32 product, so its ceiling is the 16-bit dense peak / that count (the
+        # algorithmic FLOPs stay the fp32 ones)
+        peak = BF16_MFMA_PEAK_TFLOPS / products if split else F32_MFMA_PEAK_TFLOPS
+        kname = ("igemm_k1s<%d,fwd> (%s, %dx%d tile, %s MFMA 16x16x32 x%d, f32 accumulate)"
+                 % (tile[0] // 16, "2xf16-split" if terms == 2 else "3xbf16-split", tile[0], tile[1],
+                    "f16" if terms == 2 else "bf16", products)
                  if split else "igemm_k1 (native f32 MFMA, %dx%d tile)" % (tile[0], tile[1]))
         line = {
             "metric": "pretrain clips/sec (16x112x112)", "value": clips_s, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": ("fp32 throughout; GEMM-shaped kernels autotuned per layer between the native f32 MFMA and fp32 "
-                           "operands split exactly into 3 bf16 terms with 6 bf16-MFMA products and f32 accumulation "
-                           "(4e-7 rms from fp64 per convolution, same as the native path; CSTP_GEMM=f32 forces native)"),
+            "arithmetic": ("fp32 storage and accumulation throughout; GEMM-shaped kernels autotuned per layer between the native "
+                           "f32 MFMA and the split kernels: fp32 operands scaled by a power of two and split into an f16 pair "
+                           "(22 bits), 3 f16-MFMA products per fp32 product, f32 accumulate -- 2e-7..8e-7 rms from fp64 per "
+                           "convolution vs 2e-7..1.3e-6 for the native f32 MFMA chain (profiles/r01/split_accuracy.txt); "
+                           "CSTP_GEMM=bf16x3 selects the exact 3-term bf16 split (6 products), CSTP_GEMM=f32 forces native"),
             "config": {"workload": "r21d_byol R(2+1)D-%d, B=%d clip pairs/GPU 3x%dx%dx%d, BYOL + NT-Xent(all-gather) + "
                                    "overlap-rate heads, loss_weight 0.1 1 1 0 0, clip 18, SGD; random-init weights"
                                    % (args.depth, args.batch, T, HW, HW),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak,
-                         "peak_note": ("bf16 dense 2516.6 TF/s / 6 MFMA products per fp32 product" if split
+                         "peak_note": ("16-bit MFMA dense 2516.6 TF/s / %d MFMA products per fp32 product" % products if split
                                        else "f32 MFMA dense"),
                          "frac_of_native_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH) else None,
@@ -214,6 +221,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+        if os.environ.get("CSTP_DEBUG"):
+            print("absmax cells: %r" % (ops.absmax_stats,), file=sys.stderr)
     if launched:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvDesc(ctypes.Structure):
@@ -41,12 +41,21 @@ SIGNATURES = {
     "cstp_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, POINTER(InAffine), _P, _P, c_size_t]),
     "cstp_conv3d_backward_data": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
     "cstp_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t]),
+    "cstp_conv3d_forward_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, POINTER(InAffine), _P, _P, c_size_t, _P]),
+    "cstp_conv3d_backward_data_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "cstp_conv3d_backward_weight_am": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P]),
+    "cstp_gemm_set_split_terms": (c_int32, [c_int32]),
+    "cstp_gemm_get_split_terms": (c_int32, []),
     "cstp_conv3d_query_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     "cstp_conv3d_set_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     "cstp_conv3d_autotune": (c_int32, [_P, POINTER(ConvDesc), c_int32, _P, _P, _P, _P, c_size_t, c_int32]),
     "cstp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "cstp_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                         c_float, c_float, c_int32, _P, c_size_t]),
+    "cstp_bn_forward_train_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                           c_float, c_float, c_int32, _P, c_size_t, _P]),
+    "cstp_bn_backward_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, _P, c_size_t, _P]),
     "cstp_bn_stats_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float,
                                       c_float, _P, c_size_t]),
     "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,

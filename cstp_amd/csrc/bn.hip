@@ -115,8 +115,9 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int c, int groups, int nsplit, double count,
                                        float eps, float momentum, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float2* __restrict__ ss) {
+                                       const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && cell != nullptr) *cell = 0;          // filled by the apply pass that follows
   if (ch >= c) return;
   float rm = 0.f, rv = 0.f;
   if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
@@ -144,8 +145,9 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
-                                       int nsplit) {
+                                       int nsplit, unsigned* __restrict__ cell) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && cell != nullptr) *cell = 0;          // filled by the apply pass that follows
   if (ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
   for (int g = 0; g < groups; ++g) {
@@ -165,18 +167,35 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
 //      spent ~100 VALU instructions per float4 on 64-bit divisions and was VALU- rather than HBM-bound).
 constexpr int BN_UNROLL = 4;    // vectors per thread per block
 
+// optional by-product of an apply pass: the largest magnitude of the tensor it writes (fp32 bits, sign cleared) into `cell`,
+// for the consumer convolution's 2xf16-split operand scale (cstp_conv3d_*_am).  One wave-level reduction per block-wave and
+// an atomic only when the wave beats the value the cell already shows (a stale read only costs a redundant atomic).
+__device__ __forceinline__ unsigned abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned umax4(unsigned m, const float4& v) {
+  unsigned a = abs_bits(v.x), b = abs_bits(v.y), c = abs_bits(v.z), d = abs_bits(v.w);
+  a = a > b ? a : b; c = c > d ? c : d; a = a > c ? a : c;
+  return m > a ? m : a;
+}
+__device__ __forceinline__ void absmax_commit(unsigned mx, unsigned* cell) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+  if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, mx);
+}
+
 // forward: y = act((x-mean)*invstd*gamma + beta + residual)
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                    const float* __restrict__ invstd, int c, int s, int npg, int relu, int chunks) {
+                    const float* __restrict__ invstd, int c, int s, int npg, int relu, int chunks,
+                    unsigned* __restrict__ cell) {
   constexpr int W = VEC4 ? 4 : 1;
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
   const int ch = row % c, gc = (row / c) / npg * c + ch;
   const float sc = invstd[gc] * gamma[ch];
   const float sh = beta[ch] - mean[gc] * sc;
   const size_t base = (size_t)row * s;
+  unsigned mx = 0;
 #pragma unroll
   for (int u = 0; u < BN_UNROLL; ++u) {
     const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
@@ -190,13 +209,17 @@ bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
       }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       st4(y + base + e, v);
+      mx = umax4(mx, v);
     } else {
       float v = x[base + e] * sc + sh;
       if (res != nullptr) v += res[base + e];
       if (relu) v = fmaxf(v, 0.f);
       y[base + e] = v;
+      const unsigned a = abs_bits(v);
+      mx = mx > a ? mx : a;
     }
   }
+  if (cell != nullptr) absmax_commit(mx, cell);
 }
 
 // backward: dx = gamma*invstd*(g - dbeta/cnt - xhat*dgamma/cnt); dres = g
@@ -206,8 +229,9 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                     const float* __restrict__ gsum, float* __restrict__ dx,
                     float* __restrict__ dres, int c, int s, int npg, float inv_count, int relu,
-                    const float2* __restrict__ ss, int chunks) {
+                    const float2* __restrict__ ss, int chunks, unsigned* __restrict__ cell) {
   constexpr int W = VEC4 ? 4 : 1;
+  unsigned mx = 0;
   const bool remask = relu && (y == nullptr);
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
   const int ch = row % c, gc = (row / c) / npg * c + ch;
@@ -239,14 +263,19 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
       o.z = k * (g.z - mb - (v.z - mu) * is * mg);
       o.w = k * (g.w - mb - (v.w - mu) * is * mg);
       st4(dx + base + e, o);
+      mx = umax4(mx, o);
     } else {
       float g = dy[base + e];
       if (remask) { if (!((x[base + e] * sc + sh) > 0.f)) g = 0.f; }
       else if (relu && !(y[base + e] > 0.f)) g = 0.f;
       if (dres != nullptr) dres[base + e] = g;
-      dx[base + e] = k * (g - mb - (x[base + e] - mu) * is * mg);
+      const float o = k * (g - mb - (x[base + e] - mu) * is * mg);
+      dx[base + e] = o;
+      const unsigned a = abs_bits(o);
+      mx = mx > a ? mx : a;
     }
   }
+  if (cell != nullptr) absmax_commit(mx, cell);
 }
 
 // ---- BatchNorm1d (s == 1): one thread per feature, lanes along the contiguous feature axis ------
@@ -356,6 +385,15 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
                                      const float* beta, float* running_mean, float* running_var, float* save_mean,
                                      float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
                                      int32_t groups, float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes) {
+  return cstp_bn_forward_train_am(stream, x, residual, y, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                                  scale_shift, n, c, s, groups, eps, momentum, relu, ws, ws_bytes, nullptr);
+}
+
+extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                        float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
+                                        int32_t groups, float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes,
+                                        uint32_t* y_absmax) {
   CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "null argument");
   CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
   CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
@@ -363,6 +401,7 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   CSTP_REQUIRE((size_t)npg * s > 1, "train-mode BatchNorm needs more than 1 value per channel");
   hipStream_t st = as_stream(stream);
   if (s == 1) {
+    CSTP_REQUIRE(y_absmax == nullptr, "absmax by-product: BatchNorm3d (s > 1) only");
     hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, residual, y, gamma, beta, running_mean,
                        running_var, save_mean, save_invstd, npg, groups, c, eps, momentum, relu);
     CSTP_LAUNCH_CHECK();
@@ -378,12 +417,12 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift));
+                     reinterpret_cast<float2*>(scale_shift), y_absmax);
   CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks);
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, y_absmax);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, y_absmax);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -410,8 +449,8 @@ extern "C" int cstp_bn_forward_eval(void* stream, const float* x, const float* r
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   // one "group" spanning the whole batch: the apply kernel reads mean/invstd at [channel]
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks);
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, nullptr);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, nullptr);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -434,7 +473,7 @@ extern "C" int cstp_bn_stats_train(void* stream, const float* x, const float* ga
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift));
+                     reinterpret_cast<float2*>(scale_shift), nullptr);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -443,6 +482,14 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
                                 const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
                                 float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s,
                                 int32_t groups, int32_t relu, void* ws, size_t ws_bytes) {
+  return cstp_bn_backward_am(stream, x, y, dy, gamma, save_mean, save_invstd, scale_shift, dx, dresidual, dgamma, dbeta, n, c, s,
+                             groups, relu, ws, ws_bytes, nullptr);
+}
+
+extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
+                                   float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s,
+                                   int32_t groups, int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax) {
   CSTP_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
   CSTP_REQUIRE(y != nullptr || !relu || scale_shift != nullptr, "ReLU mask needs y or scale_shift");
   CSTP_REQUIRE(y != nullptr || s > 1, "BatchNorm1d backward needs y");
@@ -451,6 +498,7 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
   const int npg = n / groups;
   hipStream_t st = as_stream(stream);
   if (s == 1) {
+    CSTP_REQUIRE(dx_absmax == nullptr, "absmax by-product: BatchNorm3d (s > 1) only");
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, y, dy, gamma, save_mean, save_invstd, dx,
                        dresidual, dgamma, dbeta, npg, groups, c, relu);
     CSTP_LAUNCH_CHECK();
@@ -466,13 +514,13 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
   if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, dx_absmax);
   CSTP_LAUNCH_CHECK();
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks);
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, dx_absmax);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, dx_absmax);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,7 @@
 // (coalesced along n, the NCDHW-contiguous axis) and double buffered in LDS.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -79,16 +80,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// dw[m][c][tap] = dwp[m][tap*Cp + c]
+// dw[m][c][tap] = dwp[m][tap*Cp + c]  (x inv_x x inv_dy: the absmax cells of the 2xf16-split kernel, else null)
+__device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, float& inv);
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int M, int cin, int ntaps,
-                                    int Cp, int Jp) {
+                                    int Cp, int Jp, const unsigned* __restrict__ xcell, const unsigned* __restrict__ dycell) {
+  float i0 = 1.f, i1 = 1.f;
+  if (xcell != nullptr) { float sc; f16_scale(*xcell, sc, i0); f16_scale(*dycell, sc, i1); }
   const size_t total = (size_t)M * cin * ntaps;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % ntaps);
     const size_t r = i / ntaps;
     const int c = (int)(r % cin);
     const int m = (int)(r / cin);
-    dw[i] = dwp[(size_t)m * Jp + tap * Cp + c];
+    dw[i] = dwp[(size_t)m * Jp + tap * Cp + c] * i0 * i1;
   }
 }
 
@@ -850,7 +854,23 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   return true;
 }
 
-static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
+// planes per operand of the split kernels: 2 = f16 pair / three products (default), 3 = bf16 triple / six products
+// (CSTP_GEMM=bf16x3); CSTP_GEMM=f32 keeps every GEMM on the native f32 MFMA kernels
+static std::atomic<int> g_split_terms{0};          // 0 = not overridden (cstp_gemm_set_split_terms)
+static int split_planes() {
+  static const int env_np = [] {
+    const char* e = getenv("CSTP_GEMM");
+    return (e != nullptr && strcmp(e, "bf16x3") == 0) ? 3 : 2;
+  }();
+  const int o = g_split_terms.load(std::memory_order_relaxed);
+  return o != 0 ? o : env_np;
+}
+// tail of the workspace: [0, 256) absmax cells of the activation operand(s), then the per-row inverse scales of the packed
+// weights (<= max(k, c) + 160 rows)
+static size_t plan_tail_bytes(const cstp_conv_desc& d) { return 256 + align_up((size_t)((d.k > d.c ? d.k : d.c) + 160) * 4, 256); }
+static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p);
+static size_t plan_ws_bytes(const cstp_conv_desc& d, const ConvPlan& p) { return plan_main_bytes(d, p) + plan_tail_bytes(d); }
+static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   // packed-operand rows are padded to the tile height (<= 160): size for the tallest padding so that any tile
   // (heuristic or tuned later) fits the workspace the caller sized once
   // (the split kernels' packed operand is three bf16 planes = 6 bytes per element)
@@ -920,10 +940,16 @@ static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const flo
 #undef CSTP_K2
 }
 
-template <bool DGRAD>
-static void launch_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src,
-                       const float* bias, float* out, int ntx, int ntm) {
-#define CSTP_K1S(MT_, NH_) hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD, NH_>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm)
+static int pack_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+template <bool DGRAD, int NP>
+static void launch_k1s_np(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src,
+                          const float* bias, float* out, int ntx, int ntm, const float* inv_a, const unsigned* bcell) {
+#define CSTP_K1S(MT_, NH_) \
+  hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD, NH_, NP>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm, inv_a, bcell)
   if (tl.wm == 2) {             // 256-column tiles: only the tall row tiles (registers: 16*MT*4 accumulators per lane)
     if (tl.mt == 8) CSTP_K1S(8, 2); else CSTP_K1S(9, 2);
     return;
@@ -940,6 +966,32 @@ static void launch_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, 
 #undef CSTP_K1S
 }
 
+static int absmax_grid(size_t n) {
+  size_t b = (n / 4 + 1023) / 1024;                   // >= 4 uint4 per thread
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+// pack the weights for the split kernel, make sure the gathered tensor's absmax cell is filled (NP == 2), launch it
+template <bool DGRAD>
+static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const cstp_conv_desc& d, int ntaps, int Kp,
+                    const float* w, const float* src, size_t src_elems, const float* bias, float* out, int ntx, int ntm,
+                    void* ws, size_t main_bytes, const uint32_t* src_absmax) {
+  if (split_planes() == 3) {
+    const size_t tot = (size_t)Kp * g.Mp;
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned short*>(ws), d.k, d.c, ntaps, g.Cp, g.Mp, Kp / 16, DGRAD ? 1 : 0);
+    launch_k1s_np<DGRAD, 3>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, nullptr, nullptr);
+    return;
+  }
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
+  float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
+  hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(g.Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
+                     d.k, d.c, ntaps, g.Cp, g.Mp, Kp / 16, DGRAD ? 1 : 0);
+  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  launch_k1s_np<DGRAD, 2>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a,
+                          src_absmax != nullptr ? src_absmax : cells);
+}
+
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
 struct InAffine { const float2* ss; int npg, groups, relu; };
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
@@ -950,11 +1002,6 @@ static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InA
   o.ss = reinterpret_cast<const float2*>(a->scale_shift);
   o.groups = a->groups; o.npg = d.n / a->groups; o.relu = a->relu ? 1 : 0;
   return 0;
-}
-
-static int pack_grid(size_t total) {
-  size_t b = (total + 255) / 256;
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 }  // namespace cstp
@@ -970,6 +1017,12 @@ extern "C" size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
 extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
                                    const float* bias, const cstp_in_affine* in_affine, float* y, void* ws,
                                    size_t ws_bytes) {
+  return cstp_conv3d_forward_am(stream, desc, x, w, bias, in_affine, y, ws, ws_bytes, nullptr);
+}
+
+extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
+                                      const float* bias, const cstp_in_affine* in_affine, float* y, void* ws,
+                                      size_t ws_bytes, const uint32_t* x_absmax) {
   CSTP_REQUIRE(desc && x && w && y && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -987,10 +1040,7 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   }
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
   const bool f_split = p.f_t.sp && !p.f_straddle;
-  if (f_split)
-    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
-                       reinterpret_cast<unsigned short*>(ws), d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp, p.f_Kp / 16, 0);
-  else
+  if (!f_split)
     hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp,
                        p.f_Kp, 0);
   Geom g;
@@ -1004,7 +1054,8 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
-  if (f_split) launch_k1s<false>(p.f_t, grid, s, g, reinterpret_cast<const uint4*>(ws), x, bias, y, ntx, ntm);
+  if (f_split) run_k1s<false>(p.f_t, grid, s, g, d, p.ntaps, p.f_Kp, w, x, (size_t)d.n * d.c * d.d * d.h * d.w, bias, y, ntx, ntm,
+                              ws, plan_main_bytes(d, p), x_absmax);
   else if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   else if (ia.ss) launch_k1<false, false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, ia.ss, ia.npg, ia.relu);
   else launch_k1<false, false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
@@ -1014,6 +1065,11 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
 
 extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
                                          float* dx, void* ws, size_t ws_bytes) {
+  return cstp_conv3d_backward_data_am(stream, desc, dy, w, dx, ws, ws_bytes, nullptr);
+}
+
+extern "C" int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
+                                            float* dx, void* ws, size_t ws_bytes, const uint32_t* dy_absmax) {
   CSTP_REQUIRE(desc && dy && w && dx && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1025,10 +1081,7 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   float* wp = reinterpret_cast<float*>(ws);
   const size_t tot = (size_t)p.d_Kp * p.d_Mp;
   const bool d_split = p.d_t.sp != 0;
-  if (d_split)
-    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
-                       reinterpret_cast<unsigned short*>(ws), d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp, p.d_Kp / 16, 1);
-  else
+  if (!d_split)
     hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp,
                        p.d_Kp, 1);
   Geom g;
@@ -1041,7 +1094,8 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
   const int d_bm = tile_bm(p.d_t), d_bn = tile_bn(p.d_t);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
-  if (d_split) launch_k1s<true>(p.d_t, grid, s, g, reinterpret_cast<const uint4*>(ws), dy, nullptr, dx, ntx, ntm);
+  if (d_split) run_k1s<true>(p.d_t, grid, s, g, d, p.ntaps, p.d_Kp, w, dy, (size_t)d.n * d.k * p.Do * p.Ho * p.Wo, nullptr, dx, ntx,
+                             ntm, ws, plan_main_bytes(d, p), dy_absmax);
   else launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);
   CSTP_LAUNCH_CHECK();
   return 0;
@@ -1050,6 +1104,12 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
 extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const float* x,
                                            const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                            size_t ws_bytes) {
+  return cstp_conv3d_backward_weight_am(stream, desc, x, in_affine, dy, dw, ws, ws_bytes, nullptr, nullptr);
+}
+
+extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x,
+                                              const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
+                                              size_t ws_bytes, const uint32_t* x_absmax, const uint32_t* dy_absmax) {
   CSTP_REQUIRE(desc && x && dy && dw && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1060,7 +1120,10 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   hipStream_t s = as_stream(stream);
   float* dwp = reinterpret_cast<float*>(ws);
   const size_t slab = (size_t)d.k * p.w_Jp * sizeof(float);
-  if (hipMemsetAsync(dwp, 0, slab, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+  // the absmax cells of the 2xf16-split kernel sit right behind the slab (256-byte aligned) and are zeroed with it
+  const size_t slab_al = align_up(slab, 256);
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + slab_al);
+  if (hipMemsetAsync(dwp, 0, slab_al + 256, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
   Geom g;
   g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;         // gather from x
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;      // reduction over dy positions
@@ -1083,13 +1146,21 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
   dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
   const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
 #define CSTP_K2_ARGS p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, ia.ss, ia.npg, ia.groups, ia.relu
+  const bool w_f16 = w_split && split_planes() == 2;
+  const unsigned* xcell = x_absmax != nullptr ? x_absmax : cells;
+  const unsigned* dycell = dy_absmax != nullptr ? dy_absmax : cells + 1;
   if (w_split) {
-    if (p.w_mt == 9)
-      hipLaunchKernelGGL((igemm_k2s<9>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else if (p.w_mt == 4)
-      hipLaunchKernelGGL((igemm_k2s<4>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
-    else
-      hipLaunchKernelGGL((igemm_k2s<8>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits);
+#define CSTP_K2S(MT_, NP_) \
+  hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell)
+    if (w_f16) {
+      const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
+      if (x_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(nx)), dim3(256), 0, s, x, nx, cells);
+      if (dy_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s, dy, ny, cells + 1);
+      if (p.w_mt == 9) CSTP_K2S(9, 2); else if (p.w_mt == 4) CSTP_K2S(4, 2); else CSTP_K2S(8, 2);
+    } else {
+      if (p.w_mt == 9) CSTP_K2S(9, 3); else if (p.w_mt == 4) CSTP_K2S(4, 3); else CSTP_K2S(8, 3);
+    }
+#undef CSTP_K2S
   } else if (p.w_straddle) {
     if (v4) launch_k2<true, true, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
     else launch_k2<true, false, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
@@ -1103,7 +1174,8 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
 #undef CSTP_K2_ARGS
   CSTP_LAUNCH_CHECK();
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp,
+                     w_f16 ? xcell : nullptr, w_f16 ? dycell : nullptr);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -1116,10 +1188,18 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   const Tile& t = mode == 0 ? p.f_t : p.d_t;
   out4[0] = tile_bm(t);
   out4[1] = tile_bn(t);
-  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? 1 : 0;
+  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? split_planes() : 0;
   out4[3] = t.tpb == 2 ? 2 : 1;
   return 0;
 }
+
+extern "C" int cstp_gemm_set_split_terms(int32_t terms) {
+  CSTP_REQUIRE(terms == 0 || terms == 2 || terms == 3, "split terms: 2 (f16 pair), 3 (bf16 triple) or 0 (environment default)");
+  g_split_terms.store(terms, std::memory_order_relaxed);
+  return 0;
+}
+
+extern "C" int32_t cstp_gemm_get_split_terms(void) { return split_planes(); }
 
 extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, const int32_t* tile4) {
   CSTP_REQUIRE(desc && tile4, "null argument");

@@ -53,6 +53,80 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- the two-term variant ("2xf16 split", NP == 2 below) ------------------------------------------------------------------
+// x * 2^s = hi + lo with hi = f16(x * 2^s), lo = f16(x * 2^s - hi) (the difference is exact in fp32): 22 significand bits, and
+//     a*b ~= ah*bh + (ah*bl + al*bh)                                        (dropped: al*bl <= 2^-22 |ab|)
+// from THREE v_mfma_f32_16x16x32_f16 -- half the matrix-pipe work, two thirds of the LDS bytes and of the split VALU work of
+// the three-term bf16 variant.  Per product the error is <= 3 * 2^-22 (operand representation 2 * 2^-22 worst case, dropped
+// term 2^-22), typically 6e-8 rms -- the size of the fp32 roundings any fp32 summation order commits (measured against fp64:
+// profiles/r01/split_accuracy.txt).  f16 has a 5-bit exponent, so every operand is scaled by a power of two (exact) that puts
+// its largest magnitude in [2^14, 2^15): per TENSOR for a gathered activation operand (absmax_kernel, or a cell its producer
+// filled), per ROW for the packed weight operand (pack_weights_split2_kernel); elements more than 2^14 below the largest
+// lose relative (never absolute: the f16 subnormal spacing is 2^-39 of the largest magnitude) precision.  The epilogue
+// multiplies the accumulators by the inverse powers of two.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, float& inv) {
+  const int e = (int)(absmax_bits >> 23) & 0xff;
+  if (e == 0 || e == 255) { scale = 1.f; inv = 1.f; return; }      // all-zero / denormal operand, or inf / nan (propagates)
+  int sh = 141 - e;                                                // |max| * 2^sh in [2^14, 2^15)
+  sh = sh > 126 ? 126 : sh;
+  scale = __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(127 - sh) << 23);
+}
+
+// two fp32 (times the operand scale) -> two packed f16 pairs
+__device__ __forceinline__ void split2h(float x0, float x1, float sc, unsigned& h, unsigned& l) {
+  f32x2 v = {x0, x1};
+  v = v * sc;
+#if CSTP_DIAG == 4      // timing only: the bf16 instruction sequence in place of the f16 one
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  f32x2 hf_ = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  f32x2 r_ = v - hf_;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r_, bf16x2));
+  return;
+#endif
+#if CSTP_DIAG == 5      // timing only: truncated hi (v_and), packed RTZ / RNE conversions, no f16 -> f32 conversion
+  f32x2 hf5 = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[0]) & 0xffffe000u),
+               __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[1]) & 0xffffe000u)};
+  f32x2 r5 = v - hf5;
+  h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf5[0], hf5[1]));
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r5, f16x2));
+  return;
+#endif
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(hh, f32x2);
+  const f16x2 ll = __builtin_convertvector(r, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
+// largest magnitude of a tensor, as fp32 bits with the sign cleared (a NaN compares above everything and propagates)
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ cell) {
+  unsigned mx = 0;
+  size_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2;      // elements in front of the first 16-byte boundary
+  head = head < n ? head : n;
+  const size_t n4 = (n - head) >> 2, tail = (n - head) & 3;
+  const u32x4* x4 = reinterpret_cast<const u32x4*>(x + head);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4 v = __builtin_nontemporal_load(x4 + i);
+    unsigned a = v[0] & 0x7fffffffu, b = v[1] & 0x7fffffffu, c = v[2] & 0x7fffffffu, d = v[3] & 0x7fffffffu;
+    a = a > b ? a : b; c = c > d ? c : d; a = a > c ? a : c;
+    mx = mx > a ? mx : a;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) mx = __builtin_bit_cast(unsigned, x[threadIdx.x]) & 0x7fffffffu;
+    if (threadIdx.x >= 64 && threadIdx.x - 64 < tail) {
+      const unsigned a = __builtin_bit_cast(unsigned, x[head + n4 * 4 + (threadIdx.x - 64)]) & 0x7fffffffu;
+      mx = mx > a ? mx : a;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+  if ((threadIdx.x & 63) == 0 && mx != 0) atomicMax(cell, mx);
+}
+
 // raw buffer resource (stride 0, bounds-checked against `bytes`): out-of-range loads return 0
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -97,19 +171,66 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
   }
 }
 
+// 2xf16 split weights: wps[group = k/16][m (Mp)][plane (2)][k%16] f16 with row m scaled by a power of two (inv_a[m] = its
+// inverse); one block per row m: largest magnitude of the row, then split and store.  Block 0 also zeroes the `ncells`
+// absmax cells of the activation operand(s), which the kernels launched next fill.
+__global__ void __launch_bounds__(256)
+pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ wps, float* __restrict__ inv_a,
+                           unsigned* __restrict__ cells, int ncells, int kout, int cin, int ntaps, int Cp, int Mp, int ngroups,
+                           int dgrad) {
+  __shared__ unsigned red[4];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (m == 0 && t < ncells) cells[t] = 0;
+  const int mreal = dgrad ? cin : kout, creal = dgrad ? kout : cin;
+  auto fetch = [&](int k) __attribute__((always_inline)) -> float {
+    const int tap = k / Cp, c = k - tap * Cp;
+    if (tap >= ntaps || m >= mreal || c >= creal) return 0.f;
+    return dgrad ? w[((size_t)c * cin + m) * ntaps + tap] : w[((size_t)m * cin + c) * ntaps + tap];
+  };
+  unsigned mx = 0;
+  for (int k = t; k < ngroups * 16; k += 256) {
+    const unsigned a = __builtin_bit_cast(unsigned, fetch(k)) & 0x7fffffffu;
+    mx = mx > a ? mx : a;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  mx = red[0] > red[1] ? red[0] : red[1];
+  { const unsigned o = red[2] > red[3] ? red[2] : red[3]; mx = mx > o ? mx : o; }
+  float sc, inv;
+  f16_scale(mx, sc, inv);
+  if (t == 0) inv_a[m] = inv;
+  for (int pi = t; pi < ngroups * 8; pi += 256) {
+    const int grp = pi >> 3, kp = pi & 7, k = grp * 16 + kp * 2;
+    unsigned h, l;
+    split2h(fetch(k), fetch(k + 1), sc, h, l);
+    unsigned* dst = wps + ((size_t)grp * Mp + m) * 16 + kp;          // 32 f16 per (group, m): plane 0 = dwords 0..7
+    dst[0] = h;
+    dst[8] = l;
+  }
+}
+
 // NH = 128-column halves per block tile (1 or 2).  NH = 2 (256 positions per block) halves the weight-operand traffic per
 // FLOP -- every block re-reads the whole packed weight matrix from L2, 6.2 of the 9.8 GB the 64->144 3x3 layer moves into
 // the CUs -- and the LDS fragment reads per MFMA; each producer thread then gathers two positions.
-template <int MT, bool DGRAD, int NH>
+// NP = planes per operand: 3 = bf16 triple (six products), 2 = f16 pair (three products; inv_a = per-row inverse scales of the
+// packed weights, bcell = largest magnitude of the gathered tensor).  The LDS image keeps its 192-byte rows either way (NP == 2
+// leaves the third plane's 64 bytes unused): the swizzle and its bank-conflict properties are those of the subset.
+template <int MT, bool DGRAD, int NH, int NP>
 __global__ void __launch_bounds__(512)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
-          float* __restrict__ out, int n_tiles_x, int n_tiles_m) {
+          float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
+          const unsigned* __restrict__ bcell) {
+  static_assert(NP == 2 || NP == 3, "planes per operand");
   constexpr int BM = 16 * MT, BN = 128 * NH;
   constexpr int NC = 2 * NH;                         // 16-column tiles per consumer wave
-  constexpr int A_CH = BM * 6;                      // 16-byte chunks per A half-tile (one 16-k group)
+  constexpr int ACPR = 2 * NP;                       // 16-byte chunks per A row and 16-k group
+  constexpr int A_CH = BM * ACPR;                    // 16-byte chunks per A half-tile (one 16-k group)
   __shared__ uint4 As[2][BM * SPL_ROW];
   __shared__ uint4 Bs[2][BN * SPL_ROW];
   __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
+  __shared__ __attribute__((aligned(16))) float inva_s[NP == 2 ? BM : 4];   // NP == 2: inverse row scales of this row tile
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // in an SGPR: everything derived from it stays scalar
@@ -187,7 +308,9 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       src_b4[h] = (unsigned)((size_t)nb * g.Cs * DHWs) * 4u;
     }
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 4));
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * 96));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wps, (unsigned)((size_t)(g.Ktot >> 4) * g.Mp * (32 * NP)));
+    float sb = 1.f;                                   // operand scale of the gathered tensor (NP == 2)
+    if (NP == 2) { float inv_unused; f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sb, inv_unused); }
     // A half-tile of my group: 16-byte chunk idc = col + 128 j of BM*6, j = 0..A_IT-1 (the last may be partial)
     constexpr int A_IT = (A_CH + 127) / 128;
     static_assert(A_IT <= 7, "A staging holds at most 7 chunks per producer thread");
@@ -199,7 +322,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     for (int j = 0; j < A_IT; ++j) {
       int idc = col + 128 * j;
       if (idc >= A_CH) idc = 0;
-      const int row = idc / 6, w6 = idc - row * 6;
+      const int row = idc / ACPR, w6 = idc - row * ACPR;
       a_lds[j] = row * SPL_ROW + (w6 >> 1) * 4 + ((g2 * 2 + (w6 & 1)) ^ spl_swz(row));
     }
     const int b_lds = col * SPL_ROW;
@@ -238,7 +361,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // issue the loads of my current group into the given register set, then advance to my next group
     auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
       const bool have = e < ngroups;                  // uniform; a missing group loads zeros (OOB offsets)
-      const unsigned sa = (unsigned)(((size_t)(tap * gpt + cg) * g.Mp + m0) * 96);
+      const unsigned sa = (unsigned)(((size_t)(tap * gpt + cg) * g.Mp + m0) * (32 * NP));
       const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
 #pragma unroll
       for (int j = 0; j < A_IT; ++j) buf_load_x4(ra[j], j == A_IT - 1 ? vlast : vfull, rs_w, sa + 2048u * j);
@@ -261,13 +384,24 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
+        uint4* brow = &Bs[buf][b_lds + 128 * h * SPL_ROW];   // the swizzle only uses row bits 1..2: the same in both halves
+        if constexpr (NP == 2) {
+          uint4 ph[2], pl[2];
+          unsigned hh, ll;
+#define CSTP_SPLITH(J, DST, F) split2h(rb[h][J], rb[h][(J) + 1], sb, hh, ll); ph[DST].F = hh; pl[DST].F = ll;
+          CSTP_SPLITH(0, 0, x) CSTP_SPLITH(2, 0, y) CSTP_SPLITH(4, 0, z) CSTP_SPLITH(6, 0, w)
+          CSTP_SPLITH(8, 1, x) CSTP_SPLITH(10, 1, y) CSTP_SPLITH(12, 1, z) CSTP_SPLITH(14, 1, w)
+#undef CSTP_SPLITH
+          brow[bq0] = ph[0]; brow[bq1] = ph[1];
+          brow[4 + bq0] = pl[0]; brow[4 + bq1] = pl[1];
+          continue;
+        }
         uint4 ph[2], pm[2], pl[2];
         unsigned hh, mm, ll;
 #define CSTP_SPLIT(J, DST, F) split2(rb[h][J], rb[h][(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
         CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
         CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
 #undef CSTP_SPLIT
-        uint4* brow = &Bs[buf][b_lds + 128 * h * SPL_ROW];   // the swizzle only uses row bits 1..2: the same in both halves
         brow[bq0] = ph[0]; brow[bq1] = ph[1];
         brow[4 + bq0] = pm[0]; brow[4 + bq1] = pm[1];
         brow[8 + bq0] = pl[0]; brow[8 + bq1] = pl[1];
@@ -336,6 +470,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][c][r] = 0.f;
 
+  if (NP == 2 && t < BM) inva_s[t] = inv_a[m0 + t];  // rows < Mp: always readable; read back after the K loop's barriers
 #if CSTP_DIAG == 1
   __syncthreads();
   for (int i = 0; i < ntiles; ++i) __syncthreads();
@@ -347,35 +482,61 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     for (int i = 0; i < ntiles; ++i) {
       const uint4* Bb = &Bs[buf][(wn * 32 * NH + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
       const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
-      bf16x8 bh[NC], bm[NC], bl[NC];
+      if constexpr (NP == 2) {
+        f16x8 bh[NC], bl[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW]);
-        bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4]);
-        bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 8]);
-      }
+        for (int c = 0; c < NC; ++c) {
+          bh[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * SPL_ROW]);
+          bl[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * SPL_ROW + 4]);
+        }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
-        const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
-        const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
+        for (int mt = 0; mt < MT; ++mt) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, Ab[mt * 16 * SPL_ROW]);
+          const f16x8 al = __builtin_bit_cast(f16x8, Ab[mt * 16 * SPL_ROW + 4]);
 #pragma unroll
-        for (int c = 0; c < NC; c += 2) {   // smallest terms first; two column tiles' accumulation chains interleaved
-          f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c + 1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c + 1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c + 1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c + 1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c + 1], a1, 0, 0, 0);
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c + 1], a1, 0, 0, 0);
-          acc[mt][c] = a0;
-          acc[mt][c + 1] = a1;
+          for (int c = 0; c < NC; c += 2) {   // small terms first; two column tiles' accumulation chains interleaved
+            f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[c + 1], a1, 0, 0, 0);
+            acc[mt][c] = a0;
+            acc[mt][c + 1] = a1;
+          }
+        }
+      } else {
+        bf16x8 bh[NC], bm[NC], bl[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW]);
+          bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4]);
+          bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 8]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
+          const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
+          const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
+#pragma unroll
+          for (int c = 0; c < NC; c += 2) {   // smallest terms first; two column tiles' accumulation chains interleaved
+            f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c + 1], a1, 0, 0, 0);
+            acc[mt][c] = a0;
+            acc[mt][c + 1] = a1;
+          }
         }
       }
       __syncthreads();
@@ -388,6 +549,20 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   const int lcol = lane & 31;
   const int q = lane >> 4;
   const bool odd = (q & 1) != 0;
+  // NP == 2: undo the operand scales (powers of two: exact).  Lane group q stores rows (q & ~1) * 4 + 0..7 of every row tile:
+  // their inverse scales come out of LDS in two 16-byte reads per row tile, outside the conditional stores.
+  f32x4 ia[NP == 2 ? MT : 1][2];
+  if (NP == 2) {
+    float sc_unused, invb;
+    f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        ia[mt][hh] = *reinterpret_cast<const f32x4*>(&inva_s[mt * 16 + (q & ~1) * 4 + hh * 4]);
+        ia[mt][hh] *= invb;
+      }
+  }
 #pragma unroll
   for (int pr = 0; pr < NH; ++pr) {
     const int n = n0 + wn * 32 * NH + pr * 32 + lcol;
@@ -418,6 +593,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
         float ve = odd ? recv : v0;
         float vo = odd ? v1 : recv;
+        if (NP == 2) { ve *= ia[mt][0][r]; vo *= ia[mt][1][r]; }
         if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
         if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
       }
@@ -439,18 +615,22 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 // with its k-rows permuted so that the same 8 rows are contiguous.  Rows m >= M, channels >= Cs and taps beyond the filter
 // are CLAMPED (finite garbage whose products land in outputs nobody reads); positions outside the split / the tensor are
 // out-of-range buffer offsets = zeros.  Tile (16*MT) x 128 outputs, K-tile 32 positions, split-K with f32 atomics as K2.
-template <int MT>
+// NP as in igemm_k1s; NP == 2: *xcell / *dycell = largest magnitude of x / dY, the slab receives the SCALED sums and
+// unpack_wgrad_kernel multiplies by the inverse powers of two.
+template <int MT, int NP>
 __global__ void __launch_bounds__(512)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
-          int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit) {
+          int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit, const unsigned* __restrict__ xcell,
+          const unsigned* __restrict__ dycell) {
   static_assert(MT == 4 || MT == 8 || MT == 9, "row tiles: 64 or 128 main rows (+16)");
+  static_assert(NP == 2 || NP == 3, "planes per operand");
   constexpr int BM = 16 * MT, BJ = 128;
   constexpr bool XTRA = MT == 9;
   constexpr int AP = MT == 4 ? 16 : 32;              // 8-byte pieces per k-row of the dY image (64 / 128 columns)
   constexpr int AR = AP / 2;                         // dY rows per producer slot (8 / 16)
-  __shared__ uint2 Am[2][3][32 * AP];
-  __shared__ uint2 Bm[2][3][32 * 32];
-  __shared__ uint2 Ax[XTRA ? 2 : 1][3][32 * 4];
+  __shared__ uint2 Am[2][NP][32 * AP];
+  __shared__ uint2 Bm[2][NP][32 * 32];
+  __shared__ uint2 Ax[XTRA ? 2 : 1][NP][32 * 4];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -528,6 +708,12 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
     const int x_slot = prow(r) * 4 + (q >> 1);       // extra image: piece q>>1, dword q&1
 
     float ra0[AR], rb0[16], rx0[2], ra1[AR], rb1[16], rx1[2];
+    float sc_x = 1.f, sc_dy = 1.f;                    // NP == 2: operand scales
+    if (NP == 2) {
+      float inv_unused;
+      f16_scale(__builtin_amdgcn_readfirstlane(*xcell), sc_x, inv_unused);
+      f16_scale(__builtin_amdgcn_readfirstlane(*dycell), sc_dy, inv_unused);
+    }
 
     auto issue_loads = [&](int i, float (&ra)[AR], float (&rb)[16], float (&rx)[2]) __attribute__((always_inline)) {
       const int n = (kt_begin + i) * 32 + r;
@@ -553,42 +739,74 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
         rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, base_x + coff[j], 0, 0));
     };
 
-    auto store16 = [&](uint2* img0, uint2* img1, uint2* img2, int slot, const float (&v)[16]) __attribute__((always_inline)) {
+    // img[p] = plane p of one operand image; sc = operand scale (NP == 2)
+    auto store16 = [&](uint2 (&img)[NP][32 * 32], int slot, const float (&v)[16], float sc) __attribute__((always_inline)) {
       // 16 columns = 4 pieces per plane; the two 16-byte halves swap with the row's bit 2
-      uint4 ph[2], pm[2], pl[2];
-      unsigned hh, mm, ll;
+      if constexpr (NP == 2) {
+        uint4 ph[2], pl[2];
+        unsigned hh, ll;
+#define CSTP_SPLITH(J, DST, F) split2h(v[J], v[(J) + 1], sc, hh, ll); ph[DST].F = hh; pl[DST].F = ll;
+        CSTP_SPLITH(0, 0, x) CSTP_SPLITH(2, 0, y) CSTP_SPLITH(4, 0, z) CSTP_SPLITH(6, 0, w)
+        CSTP_SPLITH(8, 1, x) CSTP_SPLITH(10, 1, y) CSTP_SPLITH(12, 1, z) CSTP_SPLITH(14, 1, w)
+#undef CSTP_SPLITH
+        uint4* d0 = reinterpret_cast<uint4*>(img[0] + (slot & ~3));
+        uint4* d1 = reinterpret_cast<uint4*>(img[1] + (slot & ~3));
+        d0[a_half] = ph[0]; d0[a_half ^ 1] = ph[1];
+        d1[a_half] = pl[0]; d1[a_half ^ 1] = pl[1];
+      } else {
+        uint4 ph[2], pm[2], pl[2];
+        unsigned hh, mm, ll;
 #define CSTP_SPLIT(J, DST, F) split2(v[J], v[(J) + 1], hh, mm, ll); ph[DST].F = hh; pm[DST].F = mm; pl[DST].F = ll;
-      CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
-      CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
+        CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
+        CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
 #undef CSTP_SPLIT
-      uint4* d0 = reinterpret_cast<uint4*>(img0 + (slot & ~3));
-      uint4* d1 = reinterpret_cast<uint4*>(img1 + (slot & ~3));
-      uint4* d2 = reinterpret_cast<uint4*>(img2 + (slot & ~3));
-      d0[a_half] = ph[0]; d0[a_half ^ 1] = ph[1];
-      d1[a_half] = pm[0]; d1[a_half ^ 1] = pm[1];
-      d2[a_half] = pl[0]; d2[a_half ^ 1] = pl[1];
+        uint4* d0 = reinterpret_cast<uint4*>(img[0] + (slot & ~3));
+        uint4* d1 = reinterpret_cast<uint4*>(img[1] + (slot & ~3));
+        uint4* d2 = reinterpret_cast<uint4*>(img[NP - 1] + (slot & ~3));
+        d0[a_half] = ph[0]; d0[a_half ^ 1] = ph[1];
+        d1[a_half] = pm[0]; d1[a_half ^ 1] = pm[1];
+        d2[a_half] = pl[0]; d2[a_half ^ 1] = pl[1];
+      }
     };
-    auto store8 = [&](uint2* img0, uint2* img1, uint2* img2, int slot, const float* v) __attribute__((always_inline)) {
-      uint4 ph, pm, pl;
-      unsigned hh, mm, ll;
-      split2(v[0], v[1], hh, mm, ll); ph.x = hh; pm.x = mm; pl.x = ll;
-      split2(v[2], v[3], hh, mm, ll); ph.y = hh; pm.y = mm; pl.y = ll;
-      split2(v[4], v[5], hh, mm, ll); ph.z = hh; pm.z = mm; pl.z = ll;
-      split2(v[6], v[7], hh, mm, ll); ph.w = hh; pm.w = mm; pl.w = ll;
-      *reinterpret_cast<uint4*>(img0 + (slot & ~1)) = ph;
-      *reinterpret_cast<uint4*>(img1 + (slot & ~1)) = pm;
-      *reinterpret_cast<uint4*>(img2 + (slot & ~1)) = pl;
+    auto store8 = [&](uint2 (&img)[NP][32 * AP], int slot, const float* v, float sc) __attribute__((always_inline)) {
+      if constexpr (NP == 2) {
+        uint4 ph, pl;
+        unsigned hh, ll;
+        split2h(v[0], v[1], sc, hh, ll); ph.x = hh; pl.x = ll;
+        split2h(v[2], v[3], sc, hh, ll); ph.y = hh; pl.y = ll;
+        split2h(v[4], v[5], sc, hh, ll); ph.z = hh; pl.z = ll;
+        split2h(v[6], v[7], sc, hh, ll); ph.w = hh; pl.w = ll;
+        *reinterpret_cast<uint4*>(img[0] + (slot & ~1)) = ph;
+        *reinterpret_cast<uint4*>(img[1] + (slot & ~1)) = pl;
+      } else {
+        uint4 ph, pm, pl;
+        unsigned hh, mm, ll;
+        split2(v[0], v[1], hh, mm, ll); ph.x = hh; pm.x = mm; pl.x = ll;
+        split2(v[2], v[3], hh, mm, ll); ph.y = hh; pm.y = mm; pl.y = ll;
+        split2(v[4], v[5], hh, mm, ll); ph.z = hh; pm.z = mm; pl.z = ll;
+        split2(v[6], v[7], hh, mm, ll); ph.w = hh; pm.w = mm; pl.w = ll;
+        *reinterpret_cast<uint4*>(img[0] + (slot & ~1)) = ph;
+        *reinterpret_cast<uint4*>(img[1] + (slot & ~1)) = pm;
+        *reinterpret_cast<uint4*>(img[NP - 1] + (slot & ~1)) = pl;
+      }
     };
     auto split_store = [&](int buf, const float (&ra)[AR], const float (&rb)[16], const float (&rx)[2]) __attribute__((always_inline)) {
-      if constexpr (AR == 16) store16(Am[buf][0], Am[buf][1], Am[buf][2], a_slot, reinterpret_cast<const float(&)[16]>(ra));
-      else store8(Am[buf][0], Am[buf][1], Am[buf][2], a8_slot, ra);
-      store16(Bm[buf][0], Bm[buf][1], Bm[buf][2], a_slot, rb);
+      if constexpr (AR == 16) store16(Am[buf], a_slot, reinterpret_cast<const float(&)[16]>(ra), sc_dy);
+      else store8(Am[buf], a8_slot, ra, sc_dy);
+      store16(Bm[buf], a_slot, rb, sc_x);
       if (XTRA) {
-        unsigned hh, mm, ll;
-        split2(rx[0], rx[1], hh, mm, ll);
-        reinterpret_cast<unsigned*>(&Ax[buf][0][x_slot])[q & 1] = hh;
-        reinterpret_cast<unsigned*>(&Ax[buf][1][x_slot])[q & 1] = mm;
-        reinterpret_cast<unsigned*>(&Ax[buf][2][x_slot])[q & 1] = ll;
+        if constexpr (NP == 2) {
+          unsigned hh, ll;
+          split2h(rx[0], rx[1], sc_dy, hh, ll);
+          reinterpret_cast<unsigned*>(&Ax[buf][0][x_slot])[q & 1] = hh;
+          reinterpret_cast<unsigned*>(&Ax[buf][1][x_slot])[q & 1] = ll;
+        } else {
+          unsigned hh, mm, ll;
+          split2(rx[0], rx[1], hh, mm, ll);
+          reinterpret_cast<unsigned*>(&Ax[buf][0][x_slot])[q & 1] = hh;
+          reinterpret_cast<unsigned*>(&Ax[buf][1][x_slot])[q & 1] = mm;
+          reinterpret_cast<unsigned*>(&Ax[buf][NP - 1][x_slot])[q & 1] = ll;
+        }
       }
     };
 
@@ -623,55 +841,49 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
   const int r_lo = 8 * grp + lq, r_hi = r_lo + 4;
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  auto tr_frag = [&](const uint2* img, int ct) __attribute__((always_inline)) -> bf16x8 {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto tr_frag = [&](const uint2* img, int ct) __attribute__((always_inline)) -> s16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_lo * 32 + pc(r_lo, ct * 4 + lp)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_hi * 32 + pc(r_hi, ct * 4 + lp)));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  auto tr_frag_a = [&](const uint2* img, int ct) __attribute__((always_inline)) -> bf16x8 {
+  auto tr_frag_a = [&](const uint2* img, int ct) __attribute__((always_inline)) -> s16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_lo * AP + pca(r_lo, ct * 4 + lp)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_hi * AP + pca(r_hi, ct * 4 + lp)));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  auto tr_frag_x = [&](const uint2* img) __attribute__((always_inline)) -> bf16x8 {
+  auto tr_frag_x = [&](const uint2* img) __attribute__((always_inline)) -> s16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_lo) * 4 + lp));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + prow(r_hi) * 4 + lp));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
   __syncthreads();
   int buf = 0;
   for (int i = 0; i < ntiles; ++i) {
-    bf16x8 bh[2], bm[2], bl[2];
+    s16x8 bp[NP][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      bh[c] = tr_frag(Bm[buf][0], 2 * wn + c);
-      bm[c] = tr_frag(Bm[buf][1], 2 * wn + c);
-      bl[c] = tr_frag(Bm[buf][2], 2 * wn + c);
-    }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bp[pl][c] = tr_frag(Bm[buf][pl], 2 * wn + c);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      bf16x8 ah, am, al;
-      if (XTRA && mt == 8) {
-        ah = tr_frag_x(Ax[XTRA ? buf : 0][0]); am = tr_frag_x(Ax[XTRA ? buf : 0][1]); al = tr_frag_x(Ax[XTRA ? buf : 0][2]);
-      } else {
-        ah = tr_frag_a(Am[buf][0], mt); am = tr_frag_a(Am[buf][1], mt); al = tr_frag_a(Am[buf][2], mt);
-      }
+      s16x8 ap[NP];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        ap[pl] = (XTRA && mt == 8) ? tr_frag_x(Ax[XTRA ? buf : 0][pl]) : tr_frag_a(Am[buf][pl], mt);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f32x4 a = acc[mt][c];
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[c], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[c], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[c], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[c], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[c], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[c], a, 0, 0, 0);
+        if constexpr (NP == 2) {
+#define CSTP_MM(P, Q) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ap[P]), __builtin_bit_cast(f16x8, bp[Q][c]), a, 0, 0, 0)
+          CSTP_MM(1, 0); CSTP_MM(0, 1); CSTP_MM(0, 0);
+#undef CSTP_MM
+        } else {
+#define CSTP_MM(P, Q) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[P]), __builtin_bit_cast(bf16x8, bp[Q][c]), a, 0, 0, 0)
+          CSTP_MM(NP - 1, 0); CSTP_MM(0, NP - 1); CSTP_MM(1, 1); CSTP_MM(1, 0); CSTP_MM(0, 1); CSTP_MM(0, 0);
+#undef CSTP_MM
+        }
         acc[mt][c] = a;
       }
     }

@@ -73,6 +73,12 @@ def _autotune(lib, desc, mode, src, w, out, ws):
                                    ws.data_ptr(), ws.numel(), 2), "cstp_conv3d_autotune")
 
 
+def set_split_terms(terms: int) -> None:
+    """2 = f16 pair / three MFMA products (default), 3 = bf16 triple / six products, 0 = environment default
+    (cstp_gemm_set_split_terms)."""
+    check(_lib.load().cstp_gemm_set_split_terms(int(terms)), "cstp_gemm_set_split_terms")
+
+
 def set_conv_tile(x_shape, w_shape, stride, padding, mode: int, tile) -> None:
     """Pin the kernel variant of one convolution geometry and direction (cstp_conv3d_set_tile; mode 0 forward,
     1 backward_data, 2 backward_weight) and keep the autotuner away from it.  For parity tests and A/B timing."""
@@ -134,10 +140,38 @@ def _queue_join(device: torch.device) -> None:
 # ----------------------------------------------------------------------------------------------
 # convolution / linear
 # ----------------------------------------------------------------------------------------------
+# Largest-magnitude cells (cstp_hip.h: the *_am entry points).  A BatchNorm pass leaves max |y| (forward) / max |dx| (backward) in
+# a one-element device tensor as a by-product and hangs it on the tensor it produced; the convolution that consumes that very
+# tensor object hands it to the 2xf16-split kernels, which otherwise spend one extra read of the tensor on measuring it.  The
+# attribute travels with the Python object only: any op in between (reshape, cat, add, an in-place update -- _version is
+# checked) drops it, and the kernels measure for themselves.
+FUSE_ABSMAX = os.environ.get("CSTP_FUSE_ABSMAX", "1") != "0"
+absmax_stats = {"hit": 0, "miss": 0}
+
+
+def _tag_absmax(t: torch.Tensor, cell: Optional[torch.Tensor]) -> None:
+    if cell is not None:
+        t._cstp_absmax = (cell, t._version)
+
+
+def _absmax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
+    tag = getattr(t, "_cstp_absmax", None)
+    if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+        absmax_stats["hit"] += 1
+        return tag[0]
+    absmax_stats["miss"] += 1
+    return None
+
+
+def _new_cell(like: torch.Tensor) -> Optional[torch.Tensor]:
+    return torch.empty(1, dtype=torch.int32, device=like.device) if FUSE_ABSMAX else None
+
+
 class _Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding):
         lib = _lib.load()
+        xam = _absmax_of(x)
         x = _req(x, "conv3d input")
         w = _req(w, "conv3d weight")
         desc = _desc(x.shape, w.shape, stride, padding)
@@ -151,11 +185,12 @@ class _Conv3d(torch.autograd.Function):
         timed = tm is not None and tm.match("conv3d_forward", desc)
         if timed:
             tm.start()
-        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None, y.data_ptr(),
-                                      ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
+        check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None, y.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
         if timed:
             tm.stop()
         ctx.save_for_backward(x, w)
+        ctx.x_absmax = xam
         ctx.desc = desc
         ctx.has_bias = bias is not None
         return y
@@ -165,6 +200,8 @@ class _Conv3d(torch.autograd.Function):
         lib = _lib.load()
         x, w = ctx.saved_tensors
         desc = ctx.desc
+        dyam = _absmax_of(dy)
+        xam = ctx.x_absmax
         dy = _req(dy, "conv3d grad_output")
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
         dx = dw = db = None
@@ -183,25 +220,30 @@ class _Conv3d(torch.autograd.Function):
                 dws = torch.empty_like(w)
                 if AUTOTUNE:
                     _autotune(lib, desc, 2, x, dy, dws, ws_s)
-                check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
-                                                      dws.data_ptr(), ws_s.data_ptr(), ws_s.numel()), "cstp_conv3d_backward_weight")
+                check(lib.cstp_conv3d_backward_weight_am(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
+                                                         dws.data_ptr(), ws_s.data_ptr(), ws_s.numel(), _ptr(xam), _ptr(dyam)),
+                      "cstp_conv3d_backward_weight")
                 w.grad.add_(dws)
             x.record_stream(side)
             dy.record_stream(side)
+            for cell in (xam, dyam):                   # the cells are read by the side-stream kernels too
+                if cell is not None:
+                    cell.record_stream(side)
             _queue_join(x.device)
         ws = _workspace(x.device, nbytes)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if AUTOTUNE:
                 _autotune(lib, desc, 1, dy, w, dx, ws)
-            check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
-                                                ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
+            check(lib.cstp_conv3d_backward_data_am(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _ptr(dyam)), "cstp_conv3d_backward_data")
         if ctx.needs_input_grad[1] and not side_w:
             dw = torch.empty_like(w)
             if AUTOTUNE:
                 _autotune(lib, desc, 2, x, dy, dw, ws)
-            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
-                                                  dw.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_weight")
+            check(lib.cstp_conv3d_backward_weight_am(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
+                                                     dw.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam), _ptr(dyam)),
+                  "cstp_conv3d_backward_weight")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, k = dy.shape[0], dy.shape[1]
             s = dy.numel() // (n * k)
@@ -226,6 +268,8 @@ def linear(x, w, bias=None):
 # train-mode BatchNorm (+ residual) (+ ReLU)
 # ----------------------------------------------------------------------------------------------
 class _BNAct(torch.autograd.Function):
+    _last_cell = None
+
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
         lib = _lib.load()
@@ -247,10 +291,12 @@ class _BNAct(torch.autograd.Function):
         # ReLU without a residual: backward recomputes the mask from x with the affine table instead of re-reading y
         remask = relu and res is None and s > 1
         ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device) if remask else None
-        check(lib.cstp_bn_forward_train(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                        _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), _ptr(ss),
-                                        n, c, s, groups, eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel()),
-              "cstp_bn_forward_train")
+        cell = _new_cell(x) if s > 1 else None
+        check(lib.cstp_bn_forward_train_am(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), _ptr(ss),
+                                           n, c, s, groups, eps, momentum, 1 if relu else 0, ws.data_ptr(), ws.numel(),
+                                           _ptr(cell)), "cstp_bn_forward_train")
+        _BNAct._last_cell = cell     # batch_norm_act hangs it on the tensor object apply() returns
         if remask:
             ctx.save_for_backward(x, ss, gamma, mean, invstd)
         else:
@@ -275,9 +321,12 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty_like(gamma)
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)
         ws = _workspace(x.device, nbytes)
-        check(lib.cstp_bn_backward(_stream(), x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                   invstd.data_ptr(), _ptr(ss), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
-                                   c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()), "cstp_bn_backward")
+        cell = _new_cell(x) if s > 1 else None
+        check(lib.cstp_bn_backward_am(_stream(), x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                      invstd.data_ptr(), _ptr(ss), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
+                                      c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _ptr(cell)),
+              "cstp_bn_backward")
+        _tag_absmax(dx, cell)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
@@ -285,8 +334,11 @@ def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual
                    momentum=BN_MOMENTUM, groups=1):
     """y = act(batch_norm_train(x) + residual); running stats updated in place.  ``groups`` > 1: the batch is
     that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
-    return _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
-                        int(groups))
+    y = _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
+                     int(groups))
+    _tag_absmax(y, _BNAct._last_cell)
+    _BNAct._last_cell = None
+    return y
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=BN_EPS):

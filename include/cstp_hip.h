@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 10
+#define CSTP_ABI_VERSION 11
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -70,11 +70,33 @@ int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const 
                                 const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                 size_t ws_bytes);
 
+/* The same three calls with the LARGEST MAGNITUDE of the gathered activation operand(s) supplied by the caller: each
+ * *_absmax points to one device uint32 holding the fp32 bit pattern (sign cleared) of max |element| of that tensor -- exactly
+ * what cstp_bn_forward_train_am / cstp_bn_backward_am leave behind for the tensor they write.  The 2xf16-split kernels
+ * (csrc/igemm_split.h: operands scaled by a power of two into f16 range and split into an f16 pair, three f16 MFMA
+ * products per fp32 product) need it for their operand scale; with NULL they measure it themselves with one extra read of
+ * the tensor.  Every other kernel variant ignores it.  The value must not be smaller than the true maximum (f16 overflow);
+ * a larger value costs one bit of the 22-bit operand precision per factor of two. */
+int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, const float* bias,
+                           const cstp_in_affine* in_affine, float* y, void* ws, size_t ws_bytes, const uint32_t* x_absmax);
+int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
+                                 void* ws, size_t ws_bytes, const uint32_t* dy_absmax);
+int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x, const cstp_in_affine* in_affine,
+                                   const float* dy, float* dw, void* ws, size_t ws_bytes, const uint32_t* x_absmax,
+                                   const uint32_t* dy_absmax);
+
+/* Arithmetic of the split kernels (csrc/igemm_split.h), process-wide: 2 = every fp32 operand scaled by a power of two and
+ * split into an f16 PAIR, three f16 MFMA products per fp32 product (default; 22 operand bits, measured at least as close to
+ * fp64 as the native f32 MFMA chain); 3 = split EXACTLY into a bf16 TRIPLE, six bf16 MFMA products (no operand scaling, no
+ * dynamic-range caveat; also selected by CSTP_GEMM=bf16x3 in the environment); 0 = back to the environment's choice.
+ * Both accumulate in f32. */
+int cstp_gemm_set_split_terms(int32_t terms);
+int32_t cstp_gemm_get_split_terms(void);
+
 /* Which kernel variant the next forward (mode 0) / backward_data (mode 1) call with this descriptor will run:
- * out[0] = rows per block tile, out[1] = positions per block tile, out[2] = 1 when it is the 3xbf16-split kernel (fp32
- * operands split into three bf16 terms, six bf16 MFMA products per fp32 product, f32 accumulate -- fp32-equivalent
- * arithmetic on the bf16 matrix cores, csrc/igemm_split.h) and 0 for the native f32 MFMA kernel, out[3] = K-tiles per
- * barrier.  Reporting only (bench.py names the kernel and picks the roofline peak with it). */
+ * out[0] = rows per block tile, out[1] = positions per block tile, out[2] = 0 for the native f32 MFMA kernel, else the
+ * number of terms each operand is split into by the split kernel (2 or 3, see cstp_gemm_set_split_terms), out[3] = K-tiles
+ * per barrier.  Reporting only (bench.py names the kernel and picks the roofline peak with it). */
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
 
 /* Pin the kernel variant of one geometry and direction (what cstp_conv3d_autotune would otherwise decide by timing):
@@ -112,6 +134,12 @@ int cstp_bn_forward_train(void* stream, const float* x, const float* residual, f
                           const float* beta, float* running_mean, float* running_var, float* save_mean,
                           float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
                           float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes);
+/* ... and, as a by-product of the pass that writes y (s > 1 only), the largest magnitude of y into *y_absmax (fp32 bits,
+ * sign cleared; NULL = not wanted) for the consumer convolution (cstp_conv3d_forward_am / _backward_weight_am). */
+int cstp_bn_forward_train_am(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float* save_mean,
+                             float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
+                             float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax);
 /* Statistics only: save_mean/save_invstd [groups][c], running stats update, and the affine table
  * scale_shift float[groups][c][2] = (invstd*gamma, beta - mean*invstd*gamma) that a consumer convolution
  * applies in its gather (cstp_in_affine) -- the BN output itself is never materialised. */
@@ -125,6 +153,13 @@ int cstp_bn_backward(void* stream, const float* x, const float* y, const float* 
                      const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
                      float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
                      int32_t relu, void* ws, size_t ws_bytes);
+
+/* ... with the largest magnitude of dx as a by-product (the dY operand of the producing convolution's data / weight
+ * gradient, cstp_conv3d_backward_data_am / _backward_weight_am); s > 1 only, NULL = not wanted. */
+int cstp_bn_backward_am(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
+                        const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
+                        float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
+                        int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax);
 
 /* EVAL mode (model.eval(): main_ft_mp.py:254-262 validation, test.py:74-76): the running statistics are the
  * statistics -- y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta + residual); nothing is updated.

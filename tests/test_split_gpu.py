@@ -1,8 +1,9 @@
 """Parity of EVERY GEMM kernel variant against PyTorch CPU fp64, independent of which one the autotuner would pick on the
 machine at hand: each test pins one variant for one geometry through cstp_conv3d_set_tile (C ABI) and runs forward, data
-gradient and weight gradient through the normal autograd path.  Variants: the native f32 MFMA tiles and the 3xbf16-split
-kernels (igemm_k1s row tiles 2..9 x 16, igemm_k2s 64/128/144-row tiles).  Tolerance: the 1e-4 bar of BASELINE.json (measured
-errors are ~1e-6, tools/split_accuracy.py)."""
+gradient and weight gradient through the normal autograd path.  Variants: the native f32 MFMA tiles and the split kernels
+(igemm_k1s row tiles 2..9 x 16, igemm_k2s 64/128/144-row tiles) in BOTH arithmetics -- f16 pair / three products (default) and
+bf16 triple / six products (cstp_gemm_set_split_terms).  Tolerance: the 1e-4 bar of BASELINE.json (measured errors are ~1e-6,
+tools/split_accuracy.py)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -29,14 +30,22 @@ def _rand(shape, seed):
     return torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
 
 
-def _run(name, tiles):
+@pytest.fixture(params=[2, 3], ids=["f16x2", "bf16x3"])
+def terms(request):
+    from cstp_amd import ops
+    ops.set_split_terms(request.param)
+    yield request.param
+    ops.set_split_terms(0)
+
+
+def _run(name, tiles, scale_x=1.0, scale_w=1.0, scale_dy=1.0, tol=TOL):
     """tiles: {mode: tile4}.  Returns nothing; asserts parity of y, dx, dw."""
     from cstp_amd import ops
     xs, k, ks, st, pd = GEOMS[name]
-    x = _rand(xs, 1).requires_grad_(True)
-    w = (_rand((k, xs[1]) + ks, 2) * 0.2).requires_grad_(True)
+    x = (_rand(xs, 1) * scale_x).requires_grad_(True)
+    w = (_rand((k, xs[1]) + ks, 2) * 0.2 * scale_w).requires_grad_(True)
     y = F.conv3d(x, w, None, st, pd)
-    dy = _rand(y.shape, 3)
+    dy = _rand(y.shape, 3) * scale_dy
     y.backward(dy)
     for mode, tile in tiles.items():
         ops.set_conv_tile(xs, w.shape, st, pd, mode, tile)
@@ -44,26 +53,26 @@ def _run(name, tiles):
     wg = w.detach().float().cuda().requires_grad_(True)
     yg = ops.conv3d(xg, wg, None, st, pd)
     yg.backward(dy.float().cuda())
-    assert rel_err(yg, y) < TOL, ("forward", name, tiles)
-    assert rel_err(xg.grad, x.grad) < TOL, ("backward_data", name, tiles)
-    assert rel_err(wg.grad, w.grad) < TOL, ("backward_weight", name, tiles)
+    assert rel_err(yg, y) < tol, ("forward", name, tiles)
+    assert rel_err(xg.grad, x.grad) < tol, ("backward_data", name, tiles)
+    assert rel_err(wg.grad, w.grad) < tol, ("backward_weight", name, tiles)
 
 
 @pytest.mark.parametrize("mt", [2, 3, 4, 5, 6, 8, 9])
 @pytest.mark.parametrize("name", list(GEOMS))
-def test_split_forward_and_data_gradient(name, mt):
+def test_split_forward_and_data_gradient(name, mt, terms):
     _run(name, {0: (1, mt, 0, 0), 1: (1, mt, 0, 0), 2: (0, 2, 8, 0)})
 
 
 @pytest.mark.parametrize("mt", [8, 9])
 @pytest.mark.parametrize("name", list(GEOMS))
-def test_split_256_column_tile(name, mt):
+def test_split_256_column_tile(name, mt, terms):
     _run(name, {0: (1, mt, 2, 0), 1: (1, mt, 2, 0), 2: (0, 2, 8, 0)})
 
 
 @pytest.mark.parametrize("mt,blocks", [(4, 4), (8, 8), (9, 8), (9, 16)])
 @pytest.mark.parametrize("name", list(GEOMS))
-def test_split_weight_gradient(name, mt, blocks):
+def test_split_weight_gradient(name, mt, blocks, terms):
     _run(name, {0: (0, 2, 1, 1), 1: (0, 2, 1, 1), 2: (1, mt, blocks, 0)})
 
 
@@ -82,7 +91,13 @@ def test_query_and_set_tile_roundtrip():
     desc = ops._desc(xs, (k, xs[1]) + ks, st, pd)
     out = (ctypes.c_int32 * 4)()
     _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
-    assert list(out) == [144, 128, 1, 1]
+    assert list(out) == [144, 128, lib.cstp_gemm_get_split_terms(), 1] and out[2] in (2, 3)
+    ops.set_split_terms(3)
+    _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
+    assert out[2] == 3 and lib.cstp_gemm_get_split_terms() == 3
+    ops.set_split_terms(0)
+    with pytest.raises(_lib.CstpError):
+        ops.set_split_terms(4)
     ops.set_conv_tile(xs, (k, xs[1]) + ks, st, pd, 0, (0, 2, 2, 2))
     _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
     assert list(out) == [128, 64, 0, 2]
@@ -90,3 +105,109 @@ def test_query_and_set_tile_roundtrip():
         ops.set_conv_tile(xs, (k, xs[1]) + ks, st, pd, 0, (1, 7, 0, 0))        # no 112-row split tile
     with pytest.raises(_lib.CstpError):
         ops.set_conv_tile(xs, (k, xs[1]) + ks, st, pd, 2, (1, 5, 8, 0))
+
+
+# ---- the f16-pair arithmetic: operand scales, the largest-magnitude cells, their producers ----------------------------------
+@pytest.mark.parametrize("scale_x,scale_w,scale_dy", [(1e-20, 1.0, 1e10), (3e18, 1e-12, 1e-10), (1e-3, 7e9, 1e-5),
+                                                      (1.0, 1e-25, 1e5)])
+@pytest.mark.parametrize("name", ["S1", "T2s", "lin"])
+def test_f16_pair_is_scale_invariant(name, scale_x, scale_w, scale_dy):
+    """Operands far outside f16 range: the power-of-two operand scales (per tensor for activations / gradients, per row for the
+    packed weights) bring them in, so parity holds at any magnitude fp32 itself can represent."""
+    from cstp_amd import ops
+    ops.set_split_terms(2)
+    try:
+        _run(name, {0: (1, 9, 0, 0), 1: (1, 4, 0, 0), 2: (1, 8, 8, 0)}, scale_x=scale_x, scale_w=scale_w, scale_dy=scale_dy)
+    finally:
+        ops.set_split_terms(0)
+
+
+def test_f16_pair_rows_of_very_different_magnitude():
+    """Weight rows (output channels) 12 orders of magnitude apart: each row carries its own scale, every output channel keeps
+    its relative accuracy; activations whose channels differ by 1e4 share one scale and stay within the bar."""
+    from cstp_amd import ops
+    ops.set_split_terms(2)
+    try:
+        xs, k, ks, st, pd = GEOMS["S1"]
+        x = _rand(xs, 5) * torch.logspace(-2, 2, xs[1], dtype=torch.float64).view(1, -1, 1, 1, 1)
+        w = _rand((k, xs[1]) + ks, 6) * torch.logspace(-6, 6, k, dtype=torch.float64).view(-1, 1, 1, 1, 1)
+        ops.set_conv_tile(xs, w.shape, st, pd, 0, (1, 9, 2, 0))
+        y = F.conv3d(x, w, None, st, pd)
+        yg = ops.conv3d(x.float().cuda(), w.float().cuda(), None, st, pd).double().cpu()
+        per_row = (yg - y).abs().amax(dim=(0, 2, 3, 4)) / y.abs().amax(dim=(0, 2, 3, 4))
+        assert float(per_row.max()) < TOL
+    finally:
+        ops.set_split_terms(0)
+
+
+def test_absmax_cells_from_batchnorm_feed_the_convolution():
+    """cstp_bn_forward_train_am / cstp_bn_backward_am leave max |y| / max |dx| behind; handing that cell to the convolution gives
+    the bits the self-measured path gives; a stale tag (in-place update) is dropped."""
+    from cstp_amd import ops
+    ops.set_split_terms(2)
+    try:
+        torch.manual_seed(0)
+        x = (torch.randn(4, 64, 4, 14, 14, device="cuda") * 3).requires_grad_(True)
+        g = torch.rand(64, device="cuda") + 0.5
+        b = torch.randn(64, device="cuda")
+        w = (torch.randn(144, 64, 1, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+        ops.set_conv_tile(x.shape, w.shape, (1, 1, 1), (0, 1, 1), 0, (1, 9, 0, 0))
+        ops.set_conv_tile(x.shape, w.shape, (1, 1, 1), (0, 1, 1), 1, (1, 4, 0, 0))
+        ops.set_conv_tile(x.shape, w.shape, (1, 1, 1), (0, 1, 1), 2, (1, 9, 8, 0))
+        y = ops.batch_norm_act(x, g, b, relu=True, groups=2)
+        cell, ver = y._cstp_absmax
+        assert ver == y._version
+        assert int(cell.item()) == int(y.detach().abs().max().view(torch.int32).item())       # fp32 bits of max |y|
+        before = dict(ops.absmax_stats)
+        z = ops.conv3d(y, w, None, 1, (0, 1, 1))
+        assert ops.absmax_stats["hit"] == before["hit"] + 1
+        z2 = ops.conv3d(y.detach().clone(), w.detach(), None, 1, (0, 1, 1))                     # untagged: measured inside
+        assert ops.absmax_stats["miss"] == before["miss"] + 1
+        assert torch.equal(z.detach(), z2)
+        # backward: the BN backward of a following BN tags dz; conv backward consumes it; results equal the untagged run
+        g2 = torch.rand(144, device="cuda") + 0.5
+        b2 = torch.randn(144, device="cuda")
+        out = ops.batch_norm_act(z, g2, b2, relu=True, groups=2)
+        hits = ops.absmax_stats["hit"]
+        out.square().sum().backward()
+        assert ops.absmax_stats["hit"] >= hits + 1
+        gx, gw = x.grad.clone(), w.grad.clone()
+        x.grad = None; w.grad = None
+        ops.FUSE_ABSMAX = False
+        try:
+            y = ops.batch_norm_act(x, g, b, relu=True, groups=2)
+            assert not hasattr(y, "_cstp_absmax")
+            out = ops.batch_norm_act(ops.conv3d(y, w, None, 1, (0, 1, 1)), g2, b2, relu=True, groups=2)
+            out.square().sum().backward()
+        finally:
+            ops.FUSE_ABSMAX = True
+        assert torch.equal(gx, x.grad)
+        assert rel_err(gw, w.grad) < 1e-5      # split-K f32 atomics: the summation order differs from run to run
+        # a tag does not survive an in-place update of its tensor
+        y = ops.batch_norm_act(x.detach(), g, b, relu=True, groups=2)
+        y.mul_(2.0)
+        assert ops._absmax_of(y) is None
+    finally:
+        ops.set_split_terms(0)
+
+
+def test_absmax_of_unaligned_ragged_and_zero_tensors():
+    """The self-measuring path on views that start off a 16-byte boundary, sizes that are not multiples of 4, and all-zero
+    operands (scale 1, result exactly 0)."""
+    from cstp_amd import ops
+    ops.set_split_terms(2)
+    try:
+        base = torch.randn(1 + 2 * 33 * 2 * 5 * 7, device="cuda")
+        base[17] = 900.0                                  # the maximum sits in the unaligned head / body
+        x = base[1:].view(2, 33, 2, 5, 7)
+        w = torch.randn(20, 33, 1, 3, 3, device="cuda") * 0.1
+        ops.set_conv_tile(x.shape, w.shape, (1, 1, 1), (0, 1, 1), 0, (1, 2, 0, 0))
+        y = ops.conv3d(x, w, None, 1, (0, 1, 1))
+        ref = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (0, 1, 1))
+        assert rel_err(y, ref) < TOL
+        z = ops.conv3d(torch.zeros_like(x), w, None, 1, (0, 1, 1))
+        assert float(z.abs().max()) == 0.0
+        z = ops.conv3d(x, torch.zeros_like(w), None, 1, (0, 1, 1))
+        assert float(z.abs().max()) == 0.0
+    finally:
+        ops.set_split_terms(0)

@@ -50,6 +50,8 @@ def main():
         if xs[1] < 8:
             continue
         x = torch.rand(xs, device="cuda") * 2 - 1
+        if os.environ.get("CSTP_TIME_ZERO"):         # operand of zeros: what the kernel does at the clock an idle data path allows
+            x.zero_()
         w = (torch.rand((k, xs[1]) + ks, device="cuda") * 2 - 1) * 0.05
         desc = ops._desc(xs, w.shape, st, pd)
         y = torch.empty(ops.conv_out_shape(xs, w.shape, st, pd), device="cuda")
