@@ -215,10 +215,10 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
 // FLOP -- every block re-reads the whole packed weight matrix from L2, 6.2 of the 9.8 GB the 64->144 3x3 layer moves into
 // the CUs -- and the LDS fragment reads per MFMA; each producer thread then gathers two positions.
 // NP = planes per operand: 3 = bf16 triple (six products), 2 = f16 pair (three products; inv_a = per-row inverse scales of the
-// packed weights, bcell = largest magnitude of the gathered tensor).  The LDS image keeps its 192-byte rows either way (NP == 2
-// leaves the third plane's 64 bytes unused): the swizzle and its bank-conflict properties are those of the subset.
+// packed weights, bcell = largest magnitude of the gathered tensor; 128-byte LDS rows, so the 128-column tiles fit twice
+// into a CU's LDS).
 template <int MT, bool DGRAD, int NH, int NP>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 2 : 1)      // the f16-pair 128-column tiles: two blocks per CU
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
           const unsigned* __restrict__ bcell) {
@@ -227,8 +227,15 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   constexpr int NC = 2 * NH;                         // 16-column tiles per consumer wave
   constexpr int ACPR = 2 * NP;                       // 16-byte chunks per A row and 16-k group
   constexpr int A_CH = BM * ACPR;                    // 16-byte chunks per A half-tile (one 16-k group)
-  __shared__ uint4 As[2][BM * SPL_ROW];
-  __shared__ uint4 Bs[2][BN * SPL_ROW];
+  // LDS image: NP == 3: 192-byte rows, chunk c of a plane at c ^ spl_swz(row) (see SPL_ROW); NP == 2: 128-byte rows, chunk
+  // L = 4 * plane + c at L ^ (row & 7) -- the 16 rows x 4 chunks of a fragment read and the 8 consecutive rows of a staging
+  // store each cover 16 / 8 distinct 16-byte slots of the 256-byte bank line (two rows per line).
+  constexpr int ROWC = NP == 2 ? 8 : SPL_ROW;
+  __shared__ uint4 As[2][BM * ROWC];
+  __shared__ uint4 Bs[2][BN * ROWC];
+  auto chunk_at = [](int row, int plane, int c) __attribute__((always_inline)) -> int {
+    return NP == 2 ? ((plane * 4 + c) ^ (row & 7)) : (plane * 4 + (c ^ spl_swz(row)));
+  };
   __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
   __shared__ __attribute__((aligned(16))) float inva_s[NP == 2 ? BM : 4];   // NP == 2: inverse row scales of this row tile
 
@@ -323,17 +330,20 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       int idc = col + 128 * j;
       if (idc >= A_CH) idc = 0;
       const int row = idc / ACPR, w6 = idc - row * ACPR;
-      a_lds[j] = row * SPL_ROW + (w6 >> 1) * 4 + ((g2 * 2 + (w6 & 1)) ^ spl_swz(row));
+      a_lds[j] = row * ROWC + chunk_at(row, w6 >> 1, g2 * 2 + (w6 & 1));
     }
-    const int b_lds = col * SPL_ROW;
-    const int bq0 = (g2 * 2) ^ spl_swz(col), bq1 = (g2 * 2 + 1) ^ spl_swz(col);
+    const int b_lds = col * ROWC;
+    int bq[3][2];                                     // my two chunks of every plane (the swizzle uses row bits 0..2 only:
+#pragma unroll                                        //   the same in both 128-column halves)
+    for (int pl = 0; pl < 3; ++pl) { bq[pl][0] = chunk_at(col, pl, g2 * 2); bq[pl][1] = chunk_at(col, pl, g2 * 2 + 1); }
     const unsigned ch4 = (unsigned)DHWs * 4u;         // byte stride between channels
 
     // my group sequence: e = g2, g2 + 2, ... ; (ord, cg) = (tap ordinal, 16-channel block inside the tap), kept
     // incrementally (no division in the loop)
     int ord = g2 / gpt, cg = g2 - ord * gpt;
     int e = g2;
-    unsigned vbj[NH][16];                             // per-thread byte offsets of the 16 channels at the current tap
+    unsigned vb0[NH];                                 // per-thread byte offset of channel 0 at the current tap (or OOB); the
+                                                      // channel stride rides in the scalar offset of each load
     auto set_tap = [&]() __attribute__((always_inline)) {
       const int tp = DGRAD ? __builtin_amdgcn_readfirstlane(vtap[ord < nvt ? ord : 0]) : ord;
       const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
@@ -347,9 +357,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
           id = npd[h] * g.st - g.pt + dt; ih = nph[h] * g.sh - g.ph + dh; iw = npw[h] * g.sw - g.pw + dw;
         }
         const bool ok = nvalid[h] && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
-        const unsigned vb = ok ? src_b4[h] + (unsigned)(id * HWs + ih * g.Ws + iw) * 4u : OOB;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) vbj[h][j] = vb + ch4 * j;
+        vb0[h] = ok ? src_b4[h] + (unsigned)(id * HWs + ih * g.Ws + iw) * 4u : OOB;
       }
       return tp;
     };
@@ -365,11 +373,13 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
 #pragma unroll
       for (int j = 0; j < A_IT; ++j) buf_load_x4(ra[j], j == A_IT - 1 ? vlast : vfull, rs_w, sa + 2048u * j);
-      const unsigned sb = have ? (unsigned)(cg << 4) * ch4 : OOB;   // scalar part: first channel of the block
+      const unsigned sb = have ? (unsigned)(cg << 4) * ch4 : 0u;    // scalar part: first channel of the block
 #pragma unroll
-      for (int h = 0; h < NH; ++h)
+      for (int h = 0; h < NH; ++h) {
+        const unsigned vo = have ? vb0[h] : OOB;      // the range check looks at the vector offset only
 #pragma unroll
-        for (int j = 0; j < 16; ++j) buf_load_x1(rb[h][j], have ? vbj[h][j] : OOB, rs_src, have ? sb : 0u);
+        for (int j = 0; j < 16; ++j) buf_load_x1(rb[h][j], vo, rs_src, sb + ch4 * (unsigned)j);
+      }
       e += 2;
       cg += 2;
       if (cg >= gpt) {                                // uniform: next tap(s)
@@ -384,7 +394,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        uint4* brow = &Bs[buf][b_lds + 128 * h * SPL_ROW];   // the swizzle only uses row bits 1..2: the same in both halves
+        uint4* brow = &Bs[buf][b_lds + 128 * h * ROWC];
         if constexpr (NP == 2) {
           uint4 ph[2], pl[2];
           unsigned hh, ll;
@@ -392,8 +402,8 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
           CSTP_SPLITH(0, 0, x) CSTP_SPLITH(2, 0, y) CSTP_SPLITH(4, 0, z) CSTP_SPLITH(6, 0, w)
           CSTP_SPLITH(8, 1, x) CSTP_SPLITH(10, 1, y) CSTP_SPLITH(12, 1, z) CSTP_SPLITH(14, 1, w)
 #undef CSTP_SPLITH
-          brow[bq0] = ph[0]; brow[bq1] = ph[1];
-          brow[4 + bq0] = pl[0]; brow[4 + bq1] = pl[1];
+          brow[bq[0][0]] = ph[0]; brow[bq[0][1]] = ph[1];
+          brow[bq[1][0]] = pl[0]; brow[bq[1][1]] = pl[1];
           continue;
         }
         uint4 ph[2], pm[2], pl[2];
@@ -402,9 +412,9 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         CSTP_SPLIT(0, 0, x) CSTP_SPLIT(2, 0, y) CSTP_SPLIT(4, 0, z) CSTP_SPLIT(6, 0, w)
         CSTP_SPLIT(8, 1, x) CSTP_SPLIT(10, 1, y) CSTP_SPLIT(12, 1, z) CSTP_SPLIT(14, 1, w)
 #undef CSTP_SPLIT
-        brow[bq0] = ph[0]; brow[bq1] = ph[1];
-        brow[4 + bq0] = pm[0]; brow[4 + bq1] = pm[1];
-        brow[8 + bq0] = pl[0]; brow[8 + bq1] = pl[1];
+        brow[bq[0][0]] = ph[0]; brow[bq[0][1]] = ph[1];
+        brow[bq[1][0]] = pm[0]; brow[bq[1][1]] = pm[1];
+        brow[bq[2][0]] = pl[0]; brow[bq[2][1]] = pl[1];
       }
     };
 
@@ -480,19 +490,21 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   {
     int buf = 0;
     for (int i = 0; i < ntiles; ++i) {
-      const uint4* Bb = &Bs[buf][(wn * 32 * NH + fr) * SPL_ROW + (fk ^ spl_swz(fr))];
-      const uint4* Ab = &As[buf][fr * SPL_ROW + (fk ^ spl_swz(fr))];
+      // fragment rows are fr + 16 * tile: (row & 7) == (fr & 7), so the chunk positions are per-lane constants
+      const uint4* Bb = &Bs[buf][(wn * 32 * NH + fr) * ROWC];
+      const uint4* Ab = &As[buf][fr * ROWC];
+      const int q0 = chunk_at(fr, 0, fk), q1 = chunk_at(fr, 1, fk), q2 = chunk_at(fr, 2, fk);
       if constexpr (NP == 2) {
         f16x8 bh[NC], bl[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          bh[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * SPL_ROW]);
-          bl[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * SPL_ROW + 4]);
+          bh[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * ROWC + q0]);
+          bl[c] = __builtin_bit_cast(f16x8, Bb[c * 16 * ROWC + q1]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const f16x8 ah = __builtin_bit_cast(f16x8, Ab[mt * 16 * SPL_ROW]);
-          const f16x8 al = __builtin_bit_cast(f16x8, Ab[mt * 16 * SPL_ROW + 4]);
+          const f16x8 ah = __builtin_bit_cast(f16x8, Ab[mt * 16 * ROWC + q0]);
+          const f16x8 al = __builtin_bit_cast(f16x8, Ab[mt * 16 * ROWC + q1]);
 #pragma unroll
           for (int c = 0; c < NC; c += 2) {   // small terms first; two column tiles' accumulation chains interleaved
             f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
@@ -510,15 +522,15 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         bf16x8 bh[NC], bm[NC], bl[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW]);
-          bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 4]);
-          bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * SPL_ROW + 8]);
+          bh[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * ROWC + q0]);
+          bm[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * ROWC + q1]);
+          bl[c] = __builtin_bit_cast(bf16x8, Bb[c * 16 * ROWC + q2]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW]);
-          const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 4]);
-          const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * SPL_ROW + 8]);
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, Ab[mt * 16 * ROWC + q0]);
+          const bf16x8 am = __builtin_bit_cast(bf16x8, Ab[mt * 16 * ROWC + q1]);
+          const bf16x8 al = __builtin_bit_cast(bf16x8, Ab[mt * 16 * ROWC + q2]);
 #pragma unroll
           for (int c = 0; c < NC; c += 2) {   // smallest terms first; two column tiles' accumulation chains interleaved
             f32x4 a0 = acc[mt][c], a1 = acc[mt][c + 1];
@@ -551,18 +563,8 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   const bool odd = (q & 1) != 0;
   // NP == 2: undo the operand scales (powers of two: exact).  Lane group q stores rows (q & ~1) * 4 + 0..7 of every row tile:
   // their inverse scales come out of LDS in two 16-byte reads per row tile, outside the conditional stores.
-  f32x4 ia[NP == 2 ? MT : 1][2];
-  if (NP == 2) {
-    float sc_unused, invb;
-    f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        ia[mt][hh] = *reinterpret_cast<const f32x4*>(&inva_s[mt * 16 + (q & ~1) * 4 + hh * 4]);
-        ia[mt][hh] *= invb;
-      }
-  }
+  float invb = 1.f;
+  if (NP == 2) { float sc_unused; f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb); }
 #pragma unroll
   for (int pr = 0; pr < NH; ++pr) {
     const int n = n0 + wn * 32 * NH + pr * 32 + lcol;
@@ -586,6 +588,11 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      f32x4 ia0 = {1.f, 1.f, 1.f, 1.f}, ia1 = ia0;
+      if (NP == 2) {
+        ia0 = *reinterpret_cast<const f32x4*>(&inva_s[mt * 16 + (q & ~1) * 4]) * invb;
+        ia1 = *reinterpret_cast<const f32x4*>(&inva_s[mt * 16 + (q & ~1) * 4 + 4]) * invb;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v0 = acc[mt][2 * pr][r], v1 = acc[mt][2 * pr + 1][r];
@@ -593,7 +600,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         const int m_even = m0 + mt * 16 + (q & ~1) * 4 + r, m_odd = m_even + 4;
         float ve = odd ? recv : v0;
         float vo = odd ? v1 : recv;
-        if (NP == 2) { ve *= ia[mt][0][r]; vo *= ia[mt][1][r]; }
+        if (NP == 2) { ve *= ia0[r]; vo *= ia1[r]; }
         if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
         if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
       }
