@@ -115,9 +115,8 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int c, int groups, int nsplit, double count,
                                        float eps, float momentum, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell) {
+                                       const float* __restrict__ beta, float2* __restrict__ ss) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch == 0 && cell != nullptr) *cell = 0;          // filled by the apply pass that follows
   if (ch >= c) return;
   float rm = 0.f, rv = 0.f;
   if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
@@ -145,9 +144,8 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
-                                       int nsplit, unsigned* __restrict__ cell) {
+                                       int nsplit) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch == 0 && cell != nullptr) *cell = 0;          // filled by the apply pass that follows
   if (ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
   for (int g = 0; g < groups; ++g) {
@@ -167,19 +165,37 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
 //      spent ~100 VALU instructions per float4 on 64-bit divisions and was VALU- rather than HBM-bound).
 constexpr int BN_UNROLL = 4;    // vectors per thread per block
 
-// optional by-product of an apply pass: the largest magnitude of the tensor it writes (fp32 bits, sign cleared) into `cell`,
-// for the consumer convolution's 2xf16-split operand scale (cstp_conv3d_*_am).  One wave-level reduction per block-wave and
-// an atomic only when the wave beats the value the cell already shows (a stale read only costs a redundant atomic).
+// optional by-product of an apply pass: the largest magnitude of the tensor it writes (fp32 bits, sign cleared), for the
+// consumer convolution's 2xf16-split operand scale (cstp_conv3d_*_am).  Every wave stores its own maximum into a slot of the
+// workspace (no atomics: same-address atomics execute at the memory side and serialise) and a one-block kernel folds the
+// slots into the caller's cell.
 __device__ __forceinline__ unsigned abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned umax4(unsigned m, const float4& v) {
   unsigned a = abs_bits(v.x), b = abs_bits(v.y), c = abs_bits(v.z), d = abs_bits(v.w);
   a = a > b ? a : b; c = c > d ? c : d; a = a > c ? a : c;
   return m > a ? m : a;
 }
-__device__ __forceinline__ void absmax_commit(unsigned mx, unsigned* cell) {
+__device__ __forceinline__ unsigned wave_umax(unsigned mx) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
-  if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, mx);
+  return mx;
+}
+__device__ __forceinline__ void absmax_slot(unsigned mx, unsigned* slots) {
+  mx = wave_umax(mx);
+  if ((threadIdx.x & 63) == 0) slots[blockIdx.x * 4 + (threadIdx.x >> 6)] = mx;
+}
+__global__ void __launch_bounds__(1024) absmax_fold_kernel(const unsigned* __restrict__ slots, int n, unsigned* __restrict__ cell) {
+  __shared__ unsigned red[16];
+  unsigned mx = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) { const unsigned a = slots[i]; mx = mx > a ? mx : a; }
+  mx = wave_umax(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    mx = threadIdx.x < 16 ? red[threadIdx.x] : 0u;
+    mx = wave_umax(mx);
+    if (threadIdx.x == 0) *cell = mx;
+  }
 }
 
 // forward: y = act((x-mean)*invstd*gamma + beta + residual)
@@ -219,7 +235,7 @@ bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
       mx = mx > a ? mx : a;
     }
   }
-  if (cell != nullptr) absmax_commit(mx, cell);
+  if (cell != nullptr) absmax_slot(mx, cell);
 }
 
 // backward: dx = gamma*invstd*(g - dbeta/cnt - xhat*dgamma/cnt); dres = g
@@ -275,7 +291,7 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
       mx = mx > a ? mx : a;
     }
   }
-  if (cell != nullptr) absmax_commit(mx, cell);
+  if (cell != nullptr) absmax_slot(mx, cell);
 }
 
 // ---- BatchNorm1d (s == 1): one thread per feature, lanes along the contiguous feature axis ------
@@ -372,13 +388,21 @@ __global__ void bn1d_eval_kernel(const float* __restrict__ x, const float* __res
 
 using namespace cstp;
 
+static size_t bn_slot_bytes(int n, int c, int s) { return align_up((size_t)n * c * cdiv(s, 1024) * 4 * sizeof(unsigned), 256); }
+static unsigned* bn_slots(void* ws, int n, int c, int groups) {
+  const int npg = n / groups;
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + align_up((size_t)c * groups * bn_nsplit(npg, c) * 2 * sizeof(double), 256) +
+                                     align_up((size_t)groups * c * 2 * sizeof(float), 256));
+}
+
 extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups) {
   (void)s;
   if (n <= 0 || c <= 0 || groups <= 0 || (n % groups) != 0) return 0;
   const int npg = n / groups;
   // [c][groups][nsplit][2] fp64 partials, then [groups][c][2] fp32 per-group backward sums
+  // ... then one absmax slot per wave of the apply pass (4 per block; <= n * c * ceil(s / 1024) blocks)
   return align_up((size_t)c * groups * bn_nsplit(npg, c) * 2 * sizeof(double), 256) +
-         align_up((size_t)groups * c * 2 * sizeof(float), 256);
+         align_up((size_t)groups * c * 2 * sizeof(float), 256) + bn_slot_bytes(n, c, s);
 }
 
 extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* residual, float* y, const float* gamma,
@@ -417,13 +441,18 @@ extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const floa
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift), y_absmax);
+                     reinterpret_cast<float2*>(scale_shift));
   CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, y_absmax);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, y_absmax);
+  unsigned* slots = y_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots);
   CSTP_LAUNCH_CHECK();
+  if (slots != nullptr) {
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(1), dim3(1024), 0, st, slots, (int)agrid.x * 4, y_absmax);
+    CSTP_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -473,7 +502,7 @@ extern "C" int cstp_bn_stats_train(void* stream, const float* x, const float* ga
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift), nullptr);
+                     reinterpret_cast<float2*>(scale_shift));
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -514,13 +543,18 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
   if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, dx_absmax);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
   CSTP_LAUNCH_CHECK();
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, dx_absmax);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, dx_absmax);
+  unsigned* slots = dx_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots);
   CSTP_LAUNCH_CHECK();
+  if (slots != nullptr) {
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(1), dim3(1024), 0, st, slots, (int)agrid.x * 4, dx_absmax);
+    CSTP_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -188,6 +188,7 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
     return dgrad ? w[((size_t)c * cin + m) * ntaps + tap] : w[((size_t)m * cin + c) * ntaps + tap];
   };
   unsigned mx = 0;
+#pragma unroll 4
   for (int k = t; k < ngroups * 16; k += 256) {
     const unsigned a = __builtin_bit_cast(unsigned, fetch(k)) & 0x7fffffffu;
     mx = mx > a ? mx : a;
@@ -201,6 +202,7 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
   float sc, inv;
   f16_scale(mx, sc, inv);
   if (t == 0) inv_a[m] = inv;
+#pragma unroll 4
   for (int pi = t; pi < ngroups * 8; pi += 256) {
     const int grp = pi >> 3, kp = pi & 7, k = grp * 16 + kp * 2;
     unsigned h, l;
@@ -218,7 +220,7 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
 // packed weights, bcell = largest magnitude of the gathered tensor; 128-byte LDS rows, so the 128-column tiles fit twice
 // into a CU's LDS).
 template <int MT, bool DGRAD, int NH, int NP>
-__global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 2 : 1)      // the f16-pair 128-column tiles: two blocks per CU
+__global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 4 : 1)      // the f16-pair 128-column tiles: two blocks per CU (<= 128 VGPRs)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
           const unsigned* __restrict__ bcell) {
@@ -625,7 +627,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 // NP as in igemm_k1s; NP == 2: *xcell / *dycell = largest magnitude of x / dY, the slab receives the SCALED sums and
 // unpack_wgrad_kernel multiplies by the inverse powers of two.
 template <int MT, int NP>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, NP == 2 ? 4 : 1)      // f16 pair: the LDS images fit twice into a CU (4 waves per SIMD: <= 128 VGPRs)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
           int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit, const unsigned* __restrict__ xcell,
           const unsigned* __restrict__ dycell) {
