@@ -55,7 +55,7 @@ SIGNATURES = {
     "cstp_bn_forward_train_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                            c_float, c_float, c_int32, _P, c_size_t, _P]),
     "cstp_bn_backward_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
-                                      c_int32, _P, c_size_t, _P]),
+                                      c_int32, _P, c_size_t, _P, c_int32]),
     "cstp_bn_stats_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float,
                                       c_float, _P, c_size_t]),
     "cstp_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,

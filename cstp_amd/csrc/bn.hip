@@ -144,7 +144,7 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
-                                       int nsplit) {
+                                       int nsplit, int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
@@ -156,8 +156,9 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
     gsum[(g * c + ch) * 2 + 1] = (float)s1;
     t0 += s0; t1 += s1;
   }
-  dbeta[ch] = (float)t0;                        // the affine parameters are shared by the groups
-  dgamma[ch] = (float)t1;
+  // the affine parameters are shared by the groups; accumulate: += into the caller's gradient buffers
+  dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+  dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
 }
 
 // ---- stage 3: elementwise passes.  One block = one chunk of ONE (sample, channel) row, so the per-channel
@@ -332,7 +333,8 @@ __global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, float* __restrict__ dx, float* __restrict__ dres,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, int npg, int groups, int c, int relu) {
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int npg, int groups, int c, int relu,
+                                int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
@@ -356,8 +358,8 @@ __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __rest
       dx[(r0 + r) * c + ch] = k * (gr - mb - (x[(r0 + r) * c + ch] - mu) * is * mg);
     }
   }
-  dbeta[ch] = (float)t0;
-  dgamma[ch] = (float)t1;
+  dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+  dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
 }
 
 
@@ -512,13 +514,14 @@ extern "C" int cstp_bn_backward(void* stream, const float* x, const float* y, co
                                 float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s,
                                 int32_t groups, int32_t relu, void* ws, size_t ws_bytes) {
   return cstp_bn_backward_am(stream, x, y, dy, gamma, save_mean, save_invstd, scale_shift, dx, dresidual, dgamma, dbeta, n, c, s,
-                             groups, relu, ws, ws_bytes, nullptr);
+                             groups, relu, ws, ws_bytes, nullptr, 0);
 }
 
 extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
                                    const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
                                    float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s,
-                                   int32_t groups, int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax) {
+                                   int32_t groups, int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax,
+                                   int32_t accumulate) {
   CSTP_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
   CSTP_REQUIRE(y != nullptr || !relu || scale_shift != nullptr, "ReLU mask needs y or scale_shift");
   CSTP_REQUIRE(y != nullptr || s > 1, "BatchNorm1d backward needs y");
@@ -529,7 +532,7 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
   if (s == 1) {
     CSTP_REQUIRE(dx_absmax == nullptr, "absmax by-product: BatchNorm3d (s > 1) only");
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, x, y, dy, gamma, save_mean, save_invstd, dx,
-                       dresidual, dgamma, dbeta, npg, groups, c, relu);
+                       dresidual, dgamma, dbeta, npg, groups, c, relu, accumulate ? 1 : 0);
     CSTP_LAUNCH_CHECK();
     return 0;
   }
@@ -543,7 +546,7 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
   if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0);
   CSTP_LAUNCH_CHECK();
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));

@@ -305,6 +305,7 @@ class _BNAct(torch.autograd.Function):
         ctx.relu = relu
         ctx.groups = groups
         ctx.has_res = res is not None
+        ctx.params = (gamma, beta)     # the parameter objects themselves (their .grad may be an arena slice, see backward)
         return y
 
     @staticmethod
@@ -317,16 +318,22 @@ class _BNAct(torch.autograd.Function):
         s = x.numel() // (n * c)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        # parameters whose .grad is a live slice of the flat gradient arena (cstp_amd.train): the kernel adds into it directly
+        pg, pb = ctx.params
+        direct = DIRECT_WGRAD and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and pg.is_leaf and pb.is_leaf \
+            and pg.grad is not None and pb.grad is not None and pg.grad.is_contiguous() and pb.grad.is_contiguous()
+        dgamma = pg.grad if direct else torch.empty_like(gamma)
+        dbeta = pb.grad if direct else torch.empty_like(gamma)
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)
         ws = _workspace(x.device, nbytes)
         cell = _new_cell(x) if s > 1 else None
         check(lib.cstp_bn_backward_am(_stream(), x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                       invstd.data_ptr(), _ptr(ss), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
-                                      c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _ptr(cell)),
-              "cstp_bn_backward")
+                                      c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _ptr(cell),
+                                      1 if direct else 0), "cstp_bn_backward")
         _tag_absmax(dx, cell)
+        if direct:
+            return dx, None, None, dres, None, None, None, None, None, None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 

@@ -155,11 +155,12 @@ int cstp_bn_backward(void* stream, const float* x, const float* y, const float* 
                      int32_t relu, void* ws, size_t ws_bytes);
 
 /* ... with the largest magnitude of dx as a by-product (the dY operand of the producing convolution's data / weight
- * gradient, cstp_conv3d_backward_data_am / _backward_weight_am); s > 1 only, NULL = not wanted. */
+ * gradient, cstp_conv3d_backward_data_am / _backward_weight_am); s > 1 only, NULL = not wanted.  accumulate != 0: dgamma and
+ * dbeta are ADDED to the buffers (the parameters' gradient slices of a flat arena: no separate accumulation kernel). */
 int cstp_bn_backward_am(void* stream, const float* x, const float* y, const float* dy, const float* gamma,
                         const float* save_mean, const float* save_invstd, const float* scale_shift, float* dx,
                         float* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
-                        int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax);
+                        int32_t relu, void* ws, size_t ws_bytes, uint32_t* dx_absmax, int32_t accumulate);
 
 /* EVAL mode (model.eval(): main_ft_mp.py:254-262 validation, test.py:74-76): the running statistics are the
  * statistics -- y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta + residual); nothing is updated.
