@@ -198,3 +198,69 @@ def test_full_size_properties_r18_b16():
     lhs = float((dy.double() * yy.detach().double()).sum())
     assert abs(float((u.grad.double() * u.detach().double()).sum()) - lhs) / abs(lhs) < 1e-4
     assert abs(float((wt.grad.double() * wt.detach().double()).sum()) - lhs) / abs(lhs) < 1e-4
+
+
+def test_three_gemm_arithmetics_against_the_fp64_truth_on_a_full_backward():
+    """One loss_com forward + backward of an R(2+1)D-18 at a geometry no other test uses, under the three GEMM arithmetics the
+    library has -- native f32 MFMA (analytic tiles, no autotune), exact bf16 triple (six products), f16 pair (three products,
+    the default) -- from identical weights and clips, each measured against the fp64 run of the CPU oracle.  Loss and logits
+    agree to fp32 rounding; the gradient of this network amplifies rounding noise by ~1e4 (62 train-mode BatchNorms over a
+    batch of 3: test_oracle_golden.py GRAD_SCALE), so the statement for it is comparative: neither split arithmetic sits
+    further from the truth than a small multiple of where the native f32 MFMA chain sits."""
+    from cstp_amd import ops
+    from oracle import r21d_byol_oracle as orc
+    ls = orc.layer_sizes_for_depth(18)
+    w = (0.1, 1.0, 1.0, 1.0, 1.0)
+    sd64 = orc.closed_form_state(ls, torch.float64)
+    c1, c2, lab64 = orc.closed_form_clips(3, 6, 40, torch.float64)
+    info = orc.train_step(sd64, {}, c1, c2, lab64, ls, 0.0, 0.9, 0.0, w, False)
+    truth = {k: v.double() for k, v in info["grads"].items()}
+    truth_logits = torch.stack(info["logits"][2:]).double()
+
+    sd = orc.closed_form_state(ls, torch.float32)
+    x1, x2, labels = orc.closed_form_clips(3, 6, 40, torch.float32)
+    x1, x2 = x1.cuda(), x2.cuda()
+    labels = {k: v.cuda() for k, v in labels.items()}
+
+    def run():
+        model = build_model(ls, sd)
+        arenas = model.flatten_parameters()
+        loss_byol, logits = model(x1, x2, o_type="loss_com")
+        ce = [ops.cross_entropy(logits[0], labels["spa"]), ops.cross_entropy(logits[1], labels["tem"]),
+              ops.cross_entropy(logits[2], labels["pb"]), ops.cross_entropy(logits[3], labels["pb"]),
+              ops.cross_entropy(logits[4], labels["rot1"]), ops.cross_entropy(logits[5], labels["rot2"])]
+        total = w[0] * loss_byol.mean() + w[1] * ce[0] + w[2] * ce[1] + w[3] * (ce[2] + ce[3]) + w[4] * (ce[4] + ce[5])
+        arenas["grad"].zero_()
+        total.backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters() if p.requires_grad}
+        return float(total.detach()), torch.stack([l.detach() for l in logits[2:]]).double().cpu(), grads
+
+    saved = ops.AUTOTUNE
+    try:
+        ops.AUTOTUNE = False                   # untuned geometry + no tuning call = the analytic native-f32 tiles
+        native = run()
+        ops.AUTOTUNE = True
+        ops.set_split_terms(3)
+        triple = run()
+        ops.set_split_terms(2)
+        pair = run()
+    finally:
+        ops.AUTOTUNE = saved
+        ops.set_split_terms(0)
+
+    keys = sorted(truth)
+    assert keys == sorted(native[2])
+    tvec = torch.cat([truth[k].reshape(-1) for k in keys])
+
+    def errs(r):
+        gvec = torch.cat([r[2][k].reshape(-1) for k in keys])
+        return (abs(r[0] - float(info["loss_total"])) / abs(float(info["loss_total"])),
+                float((r[1] - truth_logits).abs().max() / truth_logits.abs().max()),
+                float((gvec - tvec).norm() / tvec.norm()))
+    report = {"native f32": errs(native), "bf16 triple": errs(triple), "f16 pair": errs(pair)}
+    print("vs fp64 truth (loss, logits max, gradient L2):", report)
+    for name, (dl, dlog, dg) in report.items():
+        assert dl < 1e-5 and dlog < 1e-4, (name, report)
+    worst_native = max(report["native f32"][2], 1e-3)
+    assert report["bf16 triple"][2] < 3 * worst_native and report["f16 pair"][2] < 3 * worst_native, report

@@ -1,3 +1,6 @@
 set -e
-timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_ft_gpu.py tests/test_r3d_gpu.py -x -q 2>&1 | tail -2
-for i in 1 2; do CSTP_DEBUG=1 timeout -k 10 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-200; done
+for V in "" d6; do for T in s9 s4; do
+  echo "== variant=$V $T"
+  L=""; [ -n "$V" ] && L=$PWD/build_ab/$V.so
+  CSTP_LIB_PATH=$L CSTP_TILE=$T timeout -k 10 200 python tools/time_k1.py --only .S 2>&1 | grep -v amdgpu.ids | grep "c2\|c3.same\|c4.same\|total" | cut -c1-130
+done; done
