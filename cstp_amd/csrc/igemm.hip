@@ -1237,6 +1237,21 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
   CSTP_REQUIRE(iters >= 1 && iters <= 100, "bad iteration count");
   const cstp_conv_desc& d = *desc;
+  // The activation operands' largest magnitudes are measured ONCE here and handed to every candidate: in a training step the
+  // cells come with the tensors (BatchNorm by-product), so the candidates are timed the way they will run.
+  static unsigned* tune_cells = nullptr;
+  if (tune_cells == nullptr && hipMalloc(&tune_cells, 256) != hipSuccess) return fail("hipMalloc failed%s", "");
+  {
+    ConvPlan tp;
+    CSTP_REQUIRE(make_plan(d, tp), "invalid conv descriptor");
+    hipStream_t s0 = as_stream(stream);
+    if (hipMemsetAsync(tune_cells, 0, 8, s0) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+    const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * tp.Do * tp.Ho * tp.Wo;
+    const size_t n0 = mode == 1 ? ny : nx;            // src = dy for the data gradient, x otherwise
+    hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(n0)), dim3(256), 0, s0, src, n0, tune_cells);
+    if (mode == 2) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s0, w, ny, tune_cells + 1);
+    CSTP_LAUNCH_CHECK();
+  }
   if (mode == 2) {
     // weight gradient (src = x, w = dy, out = dw): row-tile height x split-K block target
     const bool stem = d.c < 8;
@@ -1267,7 +1282,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
       g_force_mode = 2;
       for (int it = -1; it < iters && rc2 == 0; ++it) {
         if (it == 0) (void)hipEventRecord(a0, s2);
-        rc2 = cstp_conv3d_backward_weight(stream, desc, src, nullptr, w, out, ws, ws_bytes);
+        rc2 = cstp_conv3d_backward_weight_am(stream, desc, src, nullptr, w, out, ws, ws_bytes, tune_cells, tune_cells + 1);
       }
       g_force_tile = nullptr;
       if (rc2 != 0) break;
@@ -1322,8 +1337,8 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     g_force_mode = mode;
     for (int it = -1; it < iters && rc == 0; ++it) {      // it == -1: untimed warm-up launch
       if (it == 0) (void)hipEventRecord(e0, s);
-      rc = mode == 0 ? cstp_conv3d_forward(stream, desc, src, w, nullptr, nullptr, out, ws, ws_bytes)
-                     : cstp_conv3d_backward_data(stream, desc, src, w, out, ws, ws_bytes);
+      rc = mode == 0 ? cstp_conv3d_forward_am(stream, desc, src, w, nullptr, nullptr, out, ws, ws_bytes, tune_cells)
+                     : cstp_conv3d_backward_data_am(stream, desc, src, w, out, ws, ws_bytes, tune_cells);
     }
     g_force_tile = nullptr;
     if (rc != 0) break;
