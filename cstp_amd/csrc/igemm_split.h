@@ -80,21 +80,6 @@ __device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, fl
 __device__ __forceinline__ void split2h(float x0, float x1, float sc, unsigned& h, unsigned& l) {
   f32x2 v = {x0, x1};
   v = v * sc;
-#if CSTP_DIAG == 4      // timing only: the bf16 instruction sequence in place of the f16 one
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  f32x2 hf_ = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
-  f32x2 r_ = v - hf_;
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r_, bf16x2));
-  return;
-#endif
-#if CSTP_DIAG == 5      // timing only: truncated hi (v_and), packed RTZ / RNE conversions, no f16 -> f32 conversion
-  f32x2 hf5 = {__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[0]) & 0xffffe000u),
-               __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[1]) & 0xffffe000u)};
-  f32x2 r5 = v - hf5;
-  h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(hf5[0], hf5[1]));
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r5, f16x2));
-  return;
-#endif
   const f16x2 hh = __builtin_convertvector(v, f16x2);
   const f32x2 r = v - __builtin_convertvector(hh, f32x2);
   const f16x2 ll = __builtin_convertvector(r, f16x2);
@@ -187,11 +172,25 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
     if (tap >= ntaps || m >= mreal || c >= creal) return 0.f;
     return dgrad ? w[((size_t)c * cin + m) * ntaps + tap] : w[((size_t)m * cin + c) * ntaps + tap];
   };
+  // one pass over the row: thread t owns the k-pairs t, t + 256, ... and keeps up to PAIRS of them in registers between the
+  // maximum and the split (longer rows -- K > 512 * PAIRS -- fetch the tail a second time)
+  constexpr int PAIRS = 24;
+  const int npairs = ngroups * 8;
+  float v0[PAIRS], v1[PAIRS];
   unsigned mx = 0;
-#pragma unroll 4
-  for (int k = t; k < ngroups * 16; k += 256) {
-    const unsigned a = __builtin_bit_cast(unsigned, fetch(k)) & 0x7fffffffu;
+#pragma unroll
+  for (int i = 0; i < PAIRS; ++i) {
+    const int pi = t + 256 * i;
+    v0[i] = v1[i] = 0.f;
+    if (pi < npairs) { v0[i] = fetch(2 * pi); v1[i] = fetch(2 * pi + 1); }
+    const unsigned a = __builtin_bit_cast(unsigned, v0[i]) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v1[i]) & 0x7fffffffu;
     mx = mx > a ? mx : a;
+    mx = mx > b ? mx : b;
+  }
+  for (int pi = t + 256 * PAIRS; pi < npairs; pi += 256) {
+    const unsigned a = __builtin_bit_cast(unsigned, fetch(2 * pi)) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, fetch(2 * pi + 1)) & 0x7fffffffu;
+    mx = mx > a ? mx : a;
+    mx = mx > b ? mx : b;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
@@ -202,15 +201,19 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
   float sc, inv;
   f16_scale(mx, sc, inv);
   if (t == 0) inv_a[m] = inv;
-#pragma unroll 4
-  for (int pi = t; pi < ngroups * 8; pi += 256) {
-    const int grp = pi >> 3, kp = pi & 7, k = grp * 16 + kp * 2;
+  auto put = [&](int pi, float x0, float x1) __attribute__((always_inline)) {
     unsigned h, l;
-    split2h(fetch(k), fetch(k + 1), sc, h, l);
-    unsigned* dst = wps + ((size_t)grp * Mp + m) * 16 + kp;          // 32 f16 per (group, m): plane 0 = dwords 0..7
+    split2h(x0, x1, sc, h, l);
+    unsigned* dst = wps + ((size_t)(pi >> 3) * Mp + m) * 16 + (pi & 7);       // 32 f16 per (group, m): plane 0 = dwords 0..7
     dst[0] = h;
     dst[8] = l;
+  };
+#pragma unroll
+  for (int i = 0; i < PAIRS; ++i) {
+    const int pi = t + 256 * i;
+    if (pi < npairs) put(pi, v0[i], v1[i]);
   }
+  for (int pi = t + 256 * PAIRS; pi < npairs; pi += 256) put(pi, fetch(2 * pi), fetch(2 * pi + 1));
 }
 
 // NH = 128-column halves per block tile (1 or 2).  NH = 2 (256 positions per block) halves the weight-operand traffic per
