@@ -115,8 +115,9 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, int c, int groups, int nsplit, double count,
                                        float eps, float momentum, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float2* __restrict__ ss) {
+                                       const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && cell != nullptr) *cell = 0;          // absmax_fold_kernel takes the maximum into it
   if (ch >= c) return;
   float rm = 0.f, rv = 0.f;
   if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
@@ -144,8 +145,9 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
-                                       int nsplit, int accumulate) {
+                                       int nsplit, int accumulate, unsigned* __restrict__ cell) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && cell != nullptr) *cell = 0;          // absmax_fold_kernel takes the maximum into it
   if (ch >= c) return;
   double t0 = 0.0, t1 = 0.0;
   for (int g = 0; g < groups; ++g) {
@@ -185,17 +187,25 @@ __device__ __forceinline__ void absmax_slot(unsigned mx, unsigned* slots) {
   mx = wave_umax(mx);
   if ((threadIdx.x & 63) == 0) slots[blockIdx.x * 4 + (threadIdx.x >> 6)] = mx;
 }
-__global__ void __launch_bounds__(1024) absmax_fold_kernel(const unsigned* __restrict__ slots, int n, unsigned* __restrict__ cell) {
-  __shared__ unsigned red[16];
+// FOLD_BLOCKS blocks, one atomic each into the cell the finalize kernel zeroed (a handful of atomics: no contention to speak of)
+constexpr int FOLD_BLOCKS = 32;
+__global__ void __launch_bounds__(256) absmax_fold_kernel(const unsigned* __restrict__ slots, int n, unsigned* __restrict__ cell) {
+  __shared__ unsigned red[4];
   unsigned mx = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) { const unsigned a = slots[i]; mx = mx > a ? mx : a; }
+  const uint4* s4 = reinterpret_cast<const uint4*>(slots);            // n is a multiple of 4 (4 slots per block), 256-byte aligned
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += FOLD_BLOCKS * 256) {
+    const uint4 v = s4[i];
+    unsigned a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    a = a > b ? a : b;
+    mx = mx > a ? mx : a;
+  }
   mx = wave_umax(mx);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    mx = threadIdx.x < 16 ? red[threadIdx.x] : 0u;
-    mx = wave_umax(mx);
-    if (threadIdx.x == 0) *cell = mx;
+  if (threadIdx.x == 0) {
+    unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    a = a > b ? a : b;
+    if (a != 0) atomicMax(cell, a);
   }
 }
 
@@ -443,7 +453,7 @@ extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const floa
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift));
+                     reinterpret_cast<float2*>(scale_shift), y_absmax);
   CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
@@ -452,7 +462,7 @@ extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const floa
   else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots);
   CSTP_LAUNCH_CHECK();
   if (slots != nullptr) {
-    hipLaunchKernelGGL(absmax_fold_kernel, dim3(1), dim3(1024), 0, st, slots, (int)agrid.x * 4, y_absmax);
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, y_absmax);
     CSTP_LAUNCH_CHECK();
   }
   return 0;
@@ -504,7 +514,7 @@ extern "C" int cstp_bn_stats_train(void* stream, const float* x, const float* ga
   CSTP_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
                      running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift));
+                     reinterpret_cast<float2*>(scale_shift), nullptr);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -546,7 +556,7 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
   if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0, dx_absmax);
   CSTP_LAUNCH_CHECK();
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
@@ -556,7 +566,7 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
   else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots);
   CSTP_LAUNCH_CHECK();
   if (slots != nullptr) {
-    hipLaunchKernelGGL(absmax_fold_kernel, dim3(1), dim3(1024), 0, st, slots, (int)agrid.x * 4, dx_absmax);
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, dx_absmax);
     CSTP_LAUNCH_CHECK();
   }
   return 0;
