@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=B_LOCAL)
+    ap.add_argument("--frames", type=int, default=T, help="clip length (BASELINE configs[3] uses 32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,10 +141,10 @@ def main():
     opt = FlatSGD(model.parameters(), lr=0.09, momentum=0.9, weight_decay=5e-4, arenas=arenas)
     ntx = NTXentLoss(device=dev, batch_size=args.batch * world, temperature=0.5, use_cosine_similarity=True)
     step = PretrainStep(ddp, opt, LOSS_WEIGHT, clip_grad_norm=True, ntxent=ntx, ntxent_weight=NTXENT_WEIGHT)
-    x1, x2, lab = device_batch(args.batch, T, HW, dev, seed=1 + rank)
+    x1, x2, lab = device_batch(args.batch, args.frames, HW, dev, seed=1 + rank)
 
     # S1: 64 -> 144, 1x3x3 at 16x56x56; both views of the pair share one launch (batch 2B, two BN groups)
-    timer = ConvTimer(2 * args.batch, 64, T, HW // 2, HW // 2, 144, 3)
+    timer = ConvTimer(2 * args.batch, 64, args.frames, HW // 2, HW // 2, 144, 3)
     ops.kernel_timer = timer
 
     def run(n):
@@ -173,14 +174,14 @@ def main():
         ms = 1e3 * elapsed / args.steps
         clips_s = args.batch * world * args.steps / elapsed
         k_ms = timer.mean_ms()
-        flops = 2.0 * 144 * 64 * 9 * (2 * args.batch * T * (HW // 2) * (HW // 2))   # algorithmic, per launch
+        flops = 2.0 * 144 * 64 * 9 * (2 * args.batch * args.frames * (HW // 2) * (HW // 2))   # algorithmic, per launch
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         # which kernel variant the library runs for that geometry (autotuned per geometry)
         import ctypes
         from cstp_amd import _lib
         from cstp_amd.ops import _desc
         tile = (ctypes.c_int32 * 4)()
-        d_s1 = _desc((2 * args.batch, 64, T, HW // 2, HW // 2), (144, 64, 1, 3, 3), (1, 1, 1), (0, 1, 1))
+        d_s1 = _desc((2 * args.batch, 64, args.frames, HW // 2, HW // 2), (144, 64, 1, 3, 3), (1, 1, 1), (0, 1, 1))
         _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(d_s1), 0, tile), "cstp_conv3d_query_tile")
         terms = int(tile[2])                          # 0 native f32 MFMA, 2 = f16 pair, 3 = bf16 triple
         split = terms != 0
@@ -204,15 +205,15 @@ def main():
                            "CSTP_GEMM=bf16x3 selects the exact 3-term bf16 split (6 products), CSTP_GEMM=f32 forces native"),
             "config": {"workload": "r21d_byol R(2+1)D-%d, B=%d clip pairs/GPU 3x%dx%dx%d, BYOL + NT-Xent(all-gather) + "
                                    "overlap-rate heads, loss_weight 0.1 1 1 0 0, clip 18, SGD; random-init weights"
-                                   % (args.depth, args.batch, T, HW, HW),
+                                   % (args.depth, args.batch, args.frames, HW, HW),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak,
                          "peak_note": ("16-bit MFMA dense 2516.6 TF/s / %d MFMA products per fp32 product" % products if split
                                        else "f32 MFMA dense"),
                          "frac_of_native_f32_mfma_peak": ach / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH) else None,
-                         "algorithmic_bytes_per_launch": 4.0 * (2 * args.batch * T * (HW // 2) * (HW // 2)) * (64 + 144)
+                         "traffic": pmc_traffic() if (args.batch == B_LOCAL and args.depth == DEPTH and args.frames == T) else None,
+                         "algorithmic_bytes_per_launch": 4.0 * (2 * args.batch * args.frames * (HW // 2) * (HW // 2)) * (64 + 144)
                          + 4.0 * 144 * 64 * 9,
                          "kernel": kname + "; spatial conv S1 64->144 1x3x3 @16x56x56, 2B=%d clips/launch (incl. weight pack)" % (2 * args.batch),
                          "launches_timed": len(timer.pairs), "avg_launch_ms": k_ms,
