@@ -326,13 +326,16 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // A half-tile of my group: 16-byte chunk idc = col + 128 j of BM*6, j = 0..A_IT-1 (the last may be partial)
     constexpr int A_IT = (A_CH + 127) / 128;
     static_assert(A_IT <= 7, "A staging holds at most 7 chunks per producer thread");
-    const bool a_last_ok = col + 128 * (A_IT - 1) < A_CH;
-    const unsigned va_full = (unsigned)col * 16u;
+    // NP == 2: rows in the order r, r+2, r+1, r+3 inside every group of 16 chunks (bits 2 and 3 of the chunk index swapped):
+    // the two rows an 8-lane store group touches then differ in bit 1 and land on disjoint 16-byte slots (rows r, r+1 share them)
+    const int cola = NP == 2 ? ((col & ~12) | (((col >> 2) & 1) << 3) | (((col >> 3) & 1) << 2)) : col;
+    const bool a_last_ok = cola + 128 * (A_IT - 1) < A_CH;
+    const unsigned va_full = (unsigned)cola * 16u;
     const unsigned va_last = a_last_ok ? va_full : OOB;
     int a_lds[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-      int idc = col + 128 * j;
+      int idc = cola + 128 * j;
       if (idc >= A_CH) idc = 0;
       const int row = idc / ACPR, w6 = idc - row * ACPR;
       a_lds[j] = row * ROWC + chunk_at(row, w6 >> 1, g2 * 2 + (w6 & 1));
