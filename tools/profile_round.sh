@@ -2,7 +2,6 @@
 # end-of-round evidence: kernel traces of the bench (default = overlapped streams; serial for per-kernel costs), the PMC passes
 # on the S1 forward / weight-gradient kernels, and the default bench line.  Run from the repo root on the GPU box.
 set -e
-timeout -k 10 600 python3 -m pytest tests/test_ops_gpu.py tests/test_split_gpu.py -x -q 2>&1 | tail -2
 R=$PWD
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
@@ -12,6 +11,8 @@ CSTP_OVERLAP_WGRAD=0 CSTP_OVERLAP_TARGET=0 rocprofv3 --kernel-trace --stats --ou
 cd $R
 python3 profiles/summarize.py --trace $O/trace_overlap/run_kernel_trace.csv 3 > $O/bench_last3steps_f16_overlap.txt
 python3 profiles/summarize.py --trace $O/trace_serial/run_kernel_trace.csv 3 > $O/bench_last3steps_f16_serial.txt
+cp $O/trace_overlap/run_kernel_stats.csv $O/bench_f16_overlap_kernel_stats.csv
+cp $O/trace_serial/run_kernel_stats.csv $O/bench_f16_serial_kernel_stats.csv
 rm -rf $O/trace_overlap $O/trace_serial
 bash tools/pmc_s1.sh fwd > $O/pmc_fwd.txt 2>&1
 bash tools/pmc_s1.sh wgrad > $O/pmc_wgrad.txt 2>&1
