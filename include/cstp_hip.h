@@ -100,7 +100,7 @@ int32_t cstp_gemm_get_split_terms(void);
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
 
 /* Pin the kernel variant of one geometry and direction (what cstp_conv3d_autotune would otherwise decide by timing):
- * mode 0 forward / 1 backward_data: tile[0] = 1 for the 3xbf16-split kernel (tile[1] = row tiles of 16: 2,3,4,5,6,8,9;
+ * mode 0 forward / 1 backward_data: tile[0] = 1 for the split kernel (arithmetic: cstp_gemm_set_split_terms; tile[1] = row tiles of 16: 2,3,4,5,6,8,9;
  * tile[2] = 2 selects the 256-column tile, available with 8 / 9 row tiles) or 0
  * for the native f32 kernel (tile[1] = row tiles of 32: 1..5, tile[2] = waves along rows 1|2|4, tile[3] = K-tiles per barrier
  * 1|2); mode 2 backward_weight: tile[0] = 1 split (tile[1] = 4|8|9 row tiles of 16) or 0 native (tile[1] = 1..5 row tiles of
@@ -113,7 +113,7 @@ int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, const int32_t
  * out = y), data-gradient (mode 1: src = dy, w = weights, out = dx) or weight-gradient (mode 2: src = x, w = dy,
  * out = dw; row-tile height x split-K block count) kernel for this geometry on `stream` (this call DOES synchronise)
  * and remembers the fastest in a process-wide table that later calls with the same descriptor consult.  The native
- * f32 tiles give bit-identical results among themselves; the 3xbf16-split tiles (candidates unless the environment says
+ * f32 tiles give bit-identical results among themselves; the split tiles (candidates unless the environment says
  * CSTP_GEMM=f32) differ from them in the last bits (both sit ~4e-7 rms from the fp64 result per convolution,
  * tools/split_accuracy.py).  Without tuning an analytic native-f32 choice is used.  `out` is overwritten. */
 int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, int32_t mode, const float* src, const float* w,
