@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(ctypes.Structure):
@@ -63,6 +63,8 @@ SIGNATURES = {
     "cstp_bn_eval_workspace_bytes": (c_size_t, [c_int32]),
     "cstp_bn_forward_eval": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, c_int32, _P,
                                        c_size_t]),
+    "cstp_bn_forward_eval_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, c_int32, _P,
+                                          c_size_t, _P]),
     "cstp_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_maxpool3d_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),

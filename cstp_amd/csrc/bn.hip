@@ -374,7 +374,9 @@ __global__ void bn1d_bwd_kernel(const float* __restrict__ x, const float* __rest
 
 
 // ---- eval mode: the running statistics are the statistics (r21d_byol.py cls/val/test under model.eval()) ----
-__global__ void bn_eval_prepare_kernel(const float* __restrict__ running_var, float* __restrict__ invstd, int c, float eps) {
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ running_var, float* __restrict__ invstd, int c, float eps,
+                                       unsigned* __restrict__ cell) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && cell != nullptr) *cell = 0;      // absmax_fold_kernel takes the maximum into it
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch < c) invstd[ch] = 1.0f / sqrtf(running_var[ch] + eps);
 }
@@ -473,6 +475,14 @@ extern "C" size_t cstp_bn_eval_workspace_bytes(int32_t c) { return c > 0 ? align
 extern "C" int cstp_bn_forward_eval(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                                     const float* beta, const float* running_mean, const float* running_var, int32_t n,
                                     int32_t c, int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes) {
+  return cstp_bn_forward_eval_am(stream, x, residual, y, gamma, beta, running_mean, running_var, n, c, s, eps, relu, ws, ws_bytes,
+                                 nullptr);
+}
+
+extern "C" int cstp_bn_forward_eval_am(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                       const float* beta, const float* running_mean, const float* running_var, int32_t n,
+                                       int32_t c, int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes,
+                                       uint32_t* y_absmax) {
   CSTP_REQUIRE(x && y && gamma && beta && running_mean && running_var, "null argument");
   CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
   hipStream_t st = as_stream(stream);
@@ -483,16 +493,23 @@ extern "C" int cstp_bn_forward_eval(void* stream, const float* x, const float* r
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_eval_workspace_bytes(c), "workspace too small");
+  // with the absmax by-product the workspace is the train-mode one (cstp_bn_workspace_bytes(n, c, s, 1)): [invstd][wave slots]
+  CSTP_REQUIRE(y_absmax == nullptr || ws_bytes >= cstp_bn_eval_workspace_bytes(c) + bn_slot_bytes(n, c, s), "workspace too small");
   float* invstd = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, running_var, invstd, c, eps);
+  unsigned* slots = y_absmax != nullptr ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + cstp_bn_eval_workspace_bytes(c)) : nullptr;
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, running_var, invstd, c, eps, y_absmax);
   CSTP_LAUNCH_CHECK();
   const bool v4 = (s % 4) == 0;
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   // one "group" spanning the whole batch: the apply kernel reads mean/invstd at [channel]
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, nullptr);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, nullptr);
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots);
   CSTP_LAUNCH_CHECK();
+  if (slots != nullptr) {
+    hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, y_absmax);
+    CSTP_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -363,11 +363,13 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, residual=None, re
     if res is not None and res.shape != x.shape:
         raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
     y = torch.empty_like(x)
-    ws = _workspace(x.device, lib.cstp_bn_eval_workspace_bytes(c))
-    check(lib.cstp_bn_forward_eval(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), _req(gamma, "weight").data_ptr(),
-                                   _req(beta, "bias").data_ptr(), _req(running_mean, "running_mean").data_ptr(),
-                                   _req(running_var, "running_var").data_ptr(), n, c, s, float(eps), 1 if relu else 0,
-                                   ws.data_ptr(), ws.numel()), "cstp_bn_forward_eval")
+    cell = _new_cell(x) if s > 1 else None
+    ws = _workspace(x.device, lib.cstp_bn_workspace_bytes(n, c, s, 1) if cell is not None else lib.cstp_bn_eval_workspace_bytes(c))
+    check(lib.cstp_bn_forward_eval_am(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), _req(gamma, "weight").data_ptr(),
+                                      _req(beta, "bias").data_ptr(), _req(running_mean, "running_mean").data_ptr(),
+                                      _req(running_var, "running_var").data_ptr(), n, c, s, float(eps), 1 if relu else 0,
+                                      ws.data_ptr(), ws.numel(), _ptr(cell)), "cstp_bn_forward_eval")
+    _tag_absmax(y, cell)
     return y
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 11
+#define CSTP_ABI_VERSION 12
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -169,6 +169,10 @@ size_t cstp_bn_eval_workspace_bytes(int32_t c);
 int cstp_bn_forward_eval(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                          const float* beta, const float* running_mean, const float* running_var, int32_t n, int32_t c,
                          int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes);
+/* ... with max |y| as a by-product (s > 1; see cstp_bn_forward_train_am); ws then is cstp_bn_workspace_bytes(n, c, s, 1). */
+int cstp_bn_forward_eval_am(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                            const float* beta, const float* running_mean, const float* running_var, int32_t n, int32_t c,
+                            int32_t s, float eps, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax);
 
 /* ---- AdaptiveAvgPool3d(1) (r21d_byol.py:210,222-223) and its backward ------------------- */
 int cstp_avgpool_forward(void* stream, const float* x, float* y, int32_t rows, int32_t s);
