@@ -102,8 +102,9 @@ def generate_model(opts):
         if opts.ft_begin_index != 0:    # substring match on names: the later ``module.`` prefix cannot change it
             frozen_plan = get_fine_tuning_parameters(inner, opts.ft_begin_index)
     if getattr(opts, "distributed", False):
-        # gradient all-reduce (mean) on RCCL over xGMI; BN-buffer broadcast from rank 0 at each forward kept
-        # (DDP default broadcast_buffers=True)
+        # gradient all-reduce (mean) on RCCL over xGMI.  DDP's default broadcast_buffers=True is kept, but the training
+        # steps run forward/backward under no_sync(), which stops DDP's own buffer broadcast after the first forward: they
+        # broadcast rank 0's BN buffers themselves at the top of every step (cstp_amd.train.sync_buffers)
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                           find_unused_parameters=False,
                                                           bucket_cap_mb=getattr(opts, "bucket_cap_mb", 25))

@@ -28,8 +28,11 @@ def all_gather_with_grad(z: torch.Tensor) -> torch.Tensor:
 
 
 class NTXentLoss(torch.nn.Module):
-    def __init__(self, device, batch_size, temperature, use_cosine_similarity=True, gather=True):
+    def __init__(self, device, batch_size, temperature, use_cosine_similarity=True, gather=True, kernel=None):
+        """``kernel(reps [2N, F], temperature) -> scalar``: the HIP NT-Xent kernels by default (ops.ntxent); injectable so
+        that the gather / scale logic can be driven on CPU (tests/test_dist_gloo.py)."""
         super().__init__()
+        self._kernel = kernel if kernel is not None else ops.ntxent
         if not use_cosine_similarity:
             raise NotImplementedError("the CSTP driver only builds the cosine-similarity variant (main_byol.py:195)")
         self.batch_size, self.temperature, self.device, self.gather = batch_size, temperature, device, gather
@@ -47,4 +50,4 @@ class NTXentLoss(torch.nn.Module):
             # the reference fails here too: its mask is built for 2*batch_size rows (NTXent.py:23-29,57)
             raise RuntimeError("NTXentLoss was built for batch_size=%d but got %d embeddings"
                                % (self.batch_size, zis.shape[0]))
-        return ops.ntxent(torch.cat([zjs, zis], dim=0), self.temperature)
+        return self._kernel(torch.cat([zjs, zis], dim=0), self.temperature)

@@ -36,7 +36,14 @@ class _FlatOptimizer(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 off = (p.data_ptr() - base) // 4
-                if p.device != self._p.device or off < 0 or off + p.numel() > n or (p.data_ptr() - base) % 16 != 0:
+                inside = p.device == self._p.device and off >= 0 and off + p.numel() <= n and (p.data_ptr() - base) % 16 == 0
+                if not inside and not p.requires_grad:
+                    # a frozen tensor outside the trainable arena (the EMA target network of a pre-training model, which
+                    # optim.SGD(model.parameters()) of main_byol.py:228 lists too): it keeps its INDEX in param_groups and
+                    # in the state dict -- torch gives it no state, its .grad being None -- and is never touched
+                    self._slots.append((gi, -1, 0, p.numel(), p))
+                    continue
+                if not inside:
                     raise ValueError("parameter of shape %s does not live in the flat arena -- build the optimizer from "
                                      "the parameters of a model whose flatten_parameters() produced `arenas`"
                                      % (tuple(p.shape),))
@@ -79,7 +86,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
             return self._runs
         runs = []
         for gi, off, plen, _, p in sorted(self._slots, key=lambda s: s[1]):
-            if not p.requires_grad:      # torch: .grad is None -> skipped (no decay, no momentum)
+            if not p.requires_grad or off < 0:      # torch: .grad is None -> skipped (no decay, no momentum)
                 continue
             g = self.param_groups[gi]
             hp = tuple(g[k] for k in self._hyper)
@@ -99,9 +106,8 @@ class FlatSGD(_FlatOptimizer):
     _hyper = ("lr", "momentum", "weight_decay")
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, arenas=None):
+        # frozen tensors stay listed (state-dict indices = torch.optim.SGD(model.parameters())'s); _plan skips them
         params = list(params)
-        if params and not isinstance(params[0], dict):
-            params = [p for p in params if p.requires_grad]
         # the remaining torch.optim.SGD group keys ride along (fixed at what this kernel implements) so that a
         # state_dict written here loads into torch.optim.SGD -- i.e. into the reference -- and steps there
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False,
@@ -123,7 +129,7 @@ class FlatSGD(_FlatOptimizer):
         sd = super().state_dict()
         state = {}
         for i, (_, off, _, numel, p) in enumerate(self._slots):
-            if self._steps > 0 and p.requires_grad:
+            if self._steps > 0 and p.requires_grad and off >= 0:
                 state[i] = {"momentum_buffer": self._buf[off:off + numel].view_as(p).clone()}
         sd["state"] = state
         return sd
@@ -132,7 +138,7 @@ class FlatSGD(_FlatOptimizer):
         loaded = False
         for i, (_, off, _, numel, p) in enumerate(self._slots):
             st = sd["state"].get(i, sd["state"].get(str(i)))
-            if st is not None and st.get("momentum_buffer") is not None:
+            if st is not None and st.get("momentum_buffer") is not None and off >= 0:
                 self._buf[off:off + numel].view_as(p).copy_(st["momentum_buffer"])
                 loaded = True
         self._steps = 1 if loaded else 0
@@ -149,9 +155,7 @@ class FlatAdam(_FlatOptimizer):
     _hyper = ("lr", "betas", "eps", "weight_decay")
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False, arenas=None):
-        params = list(params)
-        if params and not isinstance(params[0], dict):
-            params = [p for p in params if p.requires_grad]
+        params = list(params)       # frozen tensors stay listed, as in FlatSGD
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
                                       maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=bool(decoupled)), arenas)
@@ -175,7 +179,7 @@ class FlatAdam(_FlatOptimizer):
         sd = super().state_dict()
         state = {}
         for i, (_, off, _, numel, p) in enumerate(self._slots):
-            if self._steps > 0 and p.requires_grad:
+            if self._steps > 0 and p.requires_grad and off >= 0:
                 state[i] = {"step": torch.tensor(float(self._steps)),
                             "exp_avg": self._m[off:off + numel].view_as(p).clone(),
                             "exp_avg_sq": self._v[off:off + numel].view_as(p).clone()}
@@ -186,7 +190,7 @@ class FlatAdam(_FlatOptimizer):
         steps = 0
         for i, (_, off, _, numel, p) in enumerate(self._slots):
             st = sd["state"].get(i, sd["state"].get(str(i)))
-            if st is not None and "exp_avg" in st:
+            if st is not None and "exp_avg" in st and off >= 0:
                 self._m[off:off + numel].view_as(p).copy_(st["exp_avg"])
                 self._v[off:off + numel].view_as(p).copy_(st["exp_avg_sq"])
                 steps = max(steps, int(float(st.get("step", 0))))

@@ -45,6 +45,10 @@ def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
 
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
 def get_fine_tuning_parameters(model, ft_begin_index):
     """r21d_byol.py:10-35.  ft_begin_index 0: every parameter.  Otherwise only parameters whose NAME contains one of
     'layer<i>' (i = ft_begin_index..4) or 'classify' stay trainable -- and since this model's stages are called
@@ -379,33 +383,67 @@ class ByolBase(nn.Module):
             v = t_arena[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
-        # one int64 arena per net for the BN counters: a single add_ per forward instead of 24+
-        nbt = {}
+        # BN running statistics: ONE float arena (running_mean | running_var of every BatchNorm, modules() order) and ONE
+        # int64 arena for the num_batches_tracked counters (a single add_ per net per forward instead of 24+).  Flat, so
+        # that DDP's buffer broadcast from rank 0 (models/model.py:97-103, broadcast_buffers=True) is two collectives
+        # (broadcast_buffers_) instead of one per tensor.
+        bns = [m for m in self.modules() if isinstance(m, _BatchNorm)]
+        b_arena = torch.zeros(sum(2 * _pad4(m.num_features) for m in bns), dtype=torch.float32, device=dev)
+        o = 0
+        for m in bns:
+            for name in ("running_mean", "running_var"):
+                v = b_arena[o:o + m.num_features]
+                v.copy_(getattr(m, name))
+                setattr(m, name, v)
+                o += _pad4(m.num_features)
         if self.pretrain:
             nets = (("online", self.online_net), ("target", self.target_net), ("heads", None))
         else:
             nets = (("all", self),)    # fine-tune: every BN (encoder + cls_bn) runs once per training forward
+        groups, head_inc = [], []
         for name, net in nets:
-            mods = []
             if net is not None:
                 mods = [m for m in net.modules() if isinstance(m, _BatchNorm)]
             else:
-                head_inc = []
+                mods = []
                 for h, calls in self._head_bn_calls():
                     hm = [m for m in h.modules() if isinstance(m, _BatchNorm)]
                     mods += hm
                     head_inc += [calls] * len(hm)
-            arena = torch.zeros(len(mods), dtype=torch.long, device=dev)
+            groups.append((name, mods))
+        nbt_all = torch.zeros(sum(len(mods) for _, mods in groups), dtype=torch.long, device=dev)
+        nbt, o = {}, 0
+        for name, mods in groups:
+            arena = nbt_all[o:o + len(mods)]
             for i, m in enumerate(mods):
                 arena[i] = m.num_batches_tracked
                 m.num_batches_tracked = arena[i]
                 m._nbt_in_arena = True
             nbt[name] = arena
+            o += len(mods)
         # forward() calls per step: predictor x2, overlap_spa x1, overlap_tem x1, pb_cls x2, rotate_cls x2
         if self.pretrain:
             nbt["heads_inc"] = torch.tensor(head_inc, dtype=torch.long, device=dev)
-        self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt}
+        self._arenas = {"param": p_arena, "grad": g_arena, "target": t_arena, "n_encoder": n_enc, "nbt": nbt,
+                        "buffers": b_arena, "nbt_all": nbt_all}
         return self._arenas
+
+    def broadcast_buffers_(self, src=0, group=None):
+        """DDP's per-forward buffer broadcast (models/model.py:97-103: DistributedDataParallel default
+        broadcast_buffers=True -> rank 0's BN running statistics and counters overwrite every other rank's at the start
+        of each forward) as TWO collectives over the flat buffer arenas.  No-op without an initialised process group of
+        more than one rank.  The training steps (cstp_amd.train) call it at the top of every step because they run
+        forward/backward under ``ddp.no_sync()``, which switches DDP's own broadcast off after the first step."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return False
+        if self._arenas is not None:
+            dist.broadcast(self._arenas["buffers"], src, group=group)
+            dist.broadcast(self._arenas["nbt_all"], src, group=group)
+        else:
+            for b in self.buffers():
+                dist.broadcast(b, src, group=group)
+        return True
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)

@@ -32,6 +32,55 @@ class StepOutput:
                 "loss_pred_pb": (vals[4] + vals[5]) / 2, "loss_pred_rot": (vals[6] + vals[7]) / 2}
 
 
+class LaggedScalars:
+    """The per-iteration log scalars of main_byol.py:75-84 without a host sync on the step's critical path.
+
+    The reference all-reduces the total loss and calls ``.item()`` seven times per iteration.  Here ``push`` enqueues,
+    behind step i, one all-reduce (mean) of the total loss and ONE device->pinned-host copy of the eight scalars, records
+    an event, and returns the record of step i-1, whose event completed long ago: the driver prints iteration i-1 while
+    the GPU runs iteration i+1's kernels.  ``flush`` returns the last record at the end of the epoch."""
+
+    KEYS = ("loss", "loss_byol", "loss_pred_spa", "loss_pred_tem", "loss_pred_pb", "loss_pred_rot")
+
+    def __init__(self, device, world_size=1):
+        self.world = int(world_size)
+        self.device = device
+        self._slots = [torch.empty(8, dtype=torch.float32).pin_memory() if torch.device(device).type == "cuda"
+                       else torch.empty(8, dtype=torch.float32) for _ in range(2)]
+        self._pending = None          # (slot index, event or None, tag)
+        self._n = 0
+
+    def _read(self, pend):
+        slot, ev, tag = pend
+        if ev is not None:
+            ev.synchronize()
+        v = self._slots[slot].tolist()
+        return tag, {"loss": v[0], "loss_byol": v[1], "loss_pred_spa": v[2], "loss_pred_tem": v[3],
+                     "loss_pred_pb": (v[4] + v[5]) / 2, "loss_pred_rot": (v[6] + v[7]) / 2}
+
+    def push(self, out: "StepOutput", tag=None):
+        prev = self._read(self._pending) if self._pending is not None else None
+        total = out.loss_total.detach().reshape(1).clone()
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)          # main_byol.py:22-26 reduce_mean
+            total = total / self.world
+        vals = torch.cat([total, out.loss_byol.detach().reshape(1)] + [c.detach().reshape(1) for c in out.ce])
+        slot = self._n & 1
+        self._n += 1
+        self._slots[slot].copy_(vals, non_blocking=True)
+        ev = None
+        if vals.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = (slot, ev, tag)
+        return prev
+
+    def flush(self):
+        prev = self._read(self._pending) if self._pending is not None else None
+        self._pending = None
+        return prev
+
+
 def normalise_loss_weight(w):
     if isinstance(w, (int, float)):
         w = [float(w)]
@@ -51,15 +100,29 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def sync_buffers(model) -> bool:
+    """Rank 0's BN running statistics / counters -> every rank: what DistributedDataParallel(broadcast_buffers=True), the
+    reference's wrap (models/model.py:97-103), does at the start of EVERY forward, train or eval.  The steps below call
+    it at the top of each step; the drivers call it before validation and before a checkpoint is written."""
+    inner = model.module if hasattr(model, "module") else model
+    fn = getattr(inner, "broadcast_buffers_", None)
+    return bool(fn()) if fn is not None else False
+
+
 class PretrainStep:
     """``flat_allreduce`` (default on when the model is DDP-wrapped and its gradients live in the flat arena):
-    DDP stays the launch surface and still broadcasts the BN buffers at each forward, but its per-bucket
-    gradient reducer is bypassed (``no_sync``) in favour of one all-reduce of the gradient arena after
-    backward.  Same result (mean of per-rank gradients), no bucket copies."""
+    DDP stays the launch surface, but its per-bucket gradient reducer is bypassed (``no_sync``) in favour of one
+    all-reduce of the gradient arena after backward -- same result (mean of per-rank gradients), no bucket copies.
+    Under ``no_sync`` DDP also stops broadcasting its buffers after the first forward (``require_forward_param_sync``
+    goes False), so the step issues that broadcast itself: rank 0's BN buffers overwrite the other ranks' at the top
+    of every step (``sync_buffers``: two collectives over the flat buffer arenas), as DDP's default does at each
+    forward of the reference.  ``cross_entropy`` is injectable so that the control flow can be driven on CPU
+    (tests/test_dist_gloo.py); the product default is the HIP kernel."""
 
     def __init__(self, model, optimizer, loss_weight, task="loss_com", clip_grad_norm=True, ntxent=None,
-                 ntxent_weight=0.0, flat_allreduce=True):
+                 ntxent_weight=0.0, flat_allreduce=True, cross_entropy=None):
         self.model, self.optimizer, self.task = model, optimizer, task
+        self._ce = cross_entropy if cross_entropy is not None else ops.cross_entropy
         self.w = normalise_loss_weight(loss_weight)
         self.clip = bool(clip_grad_norm)
         self.ntxent, self.ntxent_weight = ntxent, float(ntxent_weight)
@@ -71,6 +134,8 @@ class PretrainStep:
         ops.DIRECT_WGRAD = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
+        if self._flat_grad is not None:
+            sync_buffers(self.model)                  # DDP's per-forward buffer broadcast (see the class docstring)
         sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
         with sync_ctx:
             out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
@@ -85,8 +150,9 @@ class PretrainStep:
         w = self.w
         loss_byol, logits = self.model(clip_1, clip_2, o_type=self.task)
         loss_byol = loss_byol.mean()
-        ce = [ops.cross_entropy(logits[0], spa), ops.cross_entropy(logits[1], tem), ops.cross_entropy(logits[2], pb),
-              ops.cross_entropy(logits[3], pb), ops.cross_entropy(logits[4], rot_1), ops.cross_entropy(logits[5], rot_2)]
+        xe = self._ce
+        ce = [xe(logits[0], spa), xe(logits[1], tem), xe(logits[2], pb), xe(logits[3], pb), xe(logits[4], rot_1),
+              xe(logits[5], rot_2)]
         loss_total = (w[0] * loss_byol + w[1] * ce[0] + w[2] * ce[1] + w[3] * ce[2] + w[3] * ce[3]
                       + w[4] * ce[4] + w[4] * ce[5])
         nt = None
@@ -107,9 +173,11 @@ class FineTuneStep:
     ``nn.CrossEntropyLoss()`` -> ``zero_grad`` -> ``backward`` -> ``optimizer.step()`` (no gradient clipping here).
     Returns (loss, outputs) as DEVICE tensors; the caller derives accuracy from ``outputs`` as the reference does.
     Under DDP the per-bucket reducer is bypassed (``no_sync``) and only the trainable runs of the flat gradient arena
-    are all-reduced -- for ft_fc that is the 52 K-float classifier instead of the 33 M-float encoder."""
+    are all-reduced -- for ft_fc that is the 52 K-float classifier instead of the 33 M-float encoder -- and the BN
+    buffers are broadcast from rank 0 at the top of each step (see PretrainStep)."""
 
-    def __init__(self, model, optimizer, task, flat_allreduce=True):
+    def __init__(self, model, optimizer, task, flat_allreduce=True, cross_entropy=None):
+        self._ce = cross_entropy if cross_entropy is not None else ops.cross_entropy
         if task not in ("ft_fc", "ft_all"):
             raise ValueError("o_type %r: the classifier forward serves 'ft_fc' / 'ft_all' (r21d_byol.py:394)" % (task,))
         self.model, self.optimizer, self.task = model, optimizer, task
@@ -120,10 +188,12 @@ class FineTuneStep:
         ops.DIRECT_WGRAD = arenas is not None and (self._flat or not hasattr(model, "no_sync"))
 
     def __call__(self, inputs, targets):
+        if self._flat:
+            sync_buffers(self.model)
         sync_ctx = self.model.no_sync() if self._flat else contextlib.nullcontext()
         with sync_ctx:
             outputs = self.model(inputs, o_type=self.task)
-            loss = ops.cross_entropy(outputs, targets)
+            loss = self._ce(outputs, targets)
             self.optimizer.zero_grad()
             loss.backward()
         if self._flat:

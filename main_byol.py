@@ -17,7 +17,8 @@ and optimiser step (:60-91), the per-iteration print columns (:96-117), the per-
 What differs: --dataset synthetic feeds random clips through a DataLoader; --dataset synthetic_video keeps decoded
 uint8 videos in HBM and samples / rotates / crops / resizes / flips / normalises the clip pairs on the GPU
 (cstp_amd.sampler + cstp_clip_assemble) in place of the reference's PIL worker pipeline; reading JPEG / LMDB data
-sets is out of scope; scalars are fetched from the device once per printed iteration rather than seven times.
+sets is out of scope; the log scalars reach the host through one pinned-memory copy per iteration, read one step late
+(cstp_amd.train.LaggedScalars), instead of seven .item() syncs and a blocking all-reduce per iteration.
 """
 from __future__ import annotations
 
@@ -38,15 +39,8 @@ from cstp_amd.optim import build_optimizer
 from cstp_amd.opts import parse_opts
 from cstp_amd.scheduler import CosineAnnealingWarmupRestarts
 from cstp_amd.synthetic import SyntheticClips
-from cstp_amd.train import PretrainStep
+from cstp_amd.train import LaggedScalars, PretrainStep
 from cstp_amd.utils import LOG_COLUMNS, AverageMeter, Logger
-
-
-def reduce_mean(t: torch.Tensor, world_size: int) -> torch.Tensor:
-    rt = t.clone()
-    if dist.is_initialized():
-        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-    return rt / world_size
 
 
 def build_dataset(opts):
@@ -64,37 +58,49 @@ def train_BYOL(epoch, loader, step_fn, optimizer, opts, train_logger):
     meters = {k: AverageMeter() for k in ("batch", "data", "loss", "loss_byol", "loss_pred_spa", "loss_pred_tem",
                                           "loss_pred_pb", "loss_pred_rot")}
     dev = torch.device("cuda", opts.local_rank)
+    # The log scalars (and the rank-mean of the total loss, main_byol.py:22-26,75) lag ONE step behind the launches: no
+    # host sync and no blocking collective between two steps; the columns are the reference's.
+    lagged = LaggedScalars(dev, opts.world_size)
+
+    def log_line(rec):
+        (it, n, t_batch, t_data), host = rec
+        for k in LaggedScalars.KEYS:
+            meters[k].update(host[k], n)
+        meters["batch"].update(t_batch)
+        meters["data"].update(t_data)
+        m = meters
+        print("Epoch: [{0}][{1}/{2}]\tTime {3:.3f} ({4:.3f})\tData {5:.3f} ({6:.3f})\t"
+              "Loss_byol {7:.4f} ({8:.4f})\tLoss_pred_spa {9:.4f} ({10:.4f})\tLoss_pred_tem {11:.4f} ({12:.4f})\t"
+              "Loss_pred_pb {13:.4f} ({14:.4f})\tLoss_pred_rot {15:4f} ({16:.4f})Loss_total {17:.4f} ({18:.4f})\t"
+              "Lr {19:.4}".format(epoch, it, len(loader), m["batch"].val, m["batch"].avg, m["data"].val, m["data"].avg,
+                                  m["loss_byol"].val, m["loss_byol"].avg, m["loss_pred_spa"].val, m["loss_pred_spa"].avg,
+                                  m["loss_pred_tem"].val, m["loss_pred_tem"].avg, m["loss_pred_pb"].val,
+                                  m["loss_pred_pb"].avg, m["loss_pred_rot"].val, m["loss_pred_rot"].avg, m["loss"].val,
+                                  m["loss"].avg, optimizer.param_groups[-1]["lr"]))
+
     end = time.time()
     for i, (inputs, targets) in enumerate(loader):
         if opts.max_steps and i >= opts.max_steps:
             break
-        meters["data"].update(time.time() - end)
+        t_data = time.time() - end
         clip_1 = inputs[0].to(dev, non_blocking=True)
         clip_2 = inputs[1].to(dev, non_blocking=True)
         spa, tem, pb = (targets[j].to(dev, non_blocking=True) for j in range(3))
         rot_1, rot_2 = targets[3][0].to(dev, non_blocking=True), targets[3][1].to(dev, non_blocking=True)
         out = step_fn(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
-        host = out.to_host()                       # single device->host sync for the log line
-        host["loss"] = float(reduce_mean(out.loss_total, opts.world_size))
-        n = clip_1.size(0)
-        for k in ("loss", "loss_byol", "loss_pred_spa", "loss_pred_tem", "loss_pred_pb", "loss_pred_rot"):
-            meters[k].update(host[k], n)
-        meters["batch"].update(time.time() - end)
+        t_batch = time.time() - end
         end = time.time()
-        m = meters
-        print("Epoch: [{0}][{1}/{2}]\tTime {3:.3f} ({4:.3f})\tData {5:.3f} ({6:.3f})\t"
-              "Loss_byol {7:.4f} ({8:.4f})\tLoss_pred_spa {9:.4f} ({10:.4f})\tLoss_pred_tem {11:.4f} ({12:.4f})\t"
-              "Loss_pred_pb {13:.4f} ({14:.4f})\tLoss_pred_rot {15:4f} ({16:.4f})Loss_total {17:.4f} ({18:.4f})\t"
-              "Lr {19:.4}".format(epoch, i + 1, len(loader), m["batch"].val, m["batch"].avg, m["data"].val, m["data"].avg,
-                                  m["loss_byol"].val, m["loss_byol"].avg, m["loss_pred_spa"].val, m["loss_pred_spa"].avg,
-                                  m["loss_pred_tem"].val, m["loss_pred_tem"].avg, m["loss_pred_pb"].val,
-                                  m["loss_pred_pb"].avg, m["loss_pred_rot"].val, m["loss_pred_rot"].avg, m["loss"].val,
-                                  m["loss"].avg, optimizer.param_groups[-1]["lr"]))
+        prev = lagged.push(out, (i + 1, clip_1.size(0), t_batch, t_data))
+        if prev is not None:
+            log_line(prev)
+    last = lagged.flush()
+    if last is not None:
+        log_line(last)
     if opts.local_rank == 0:
         row = {k: meters[k].avg for k in LOG_COLUMNS if k in meters}
         row.update({"epoch": epoch, "acc": None, "lr": float("{:.5f}".format(optimizer.param_groups[-1]["lr"]))})
         train_logger.log(row)
-        if opts.rank == 0 and epoch % 100 == 0:
+        if opts.rank == 0 and epoch % 100 == 0:     # rank 0 writes its own state: what DDP's broadcast hands every rank
             path = os.path.join(opts.result_path, opts.dataset, opts.task, "save_{}.pth".format(epoch))
             torch.save({"epoch": epoch + 1, "arch": opts.arch, "state_dict": step_fn.model.state_dict(),
                         "optimizer": optimizer.state_dict()}, path)

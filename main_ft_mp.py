@@ -12,7 +12,7 @@ checkpoint handling per task (:106), sgd / adamw(betas 0.9,0.99) / adam (:133-14
 patience=--lr_patience) stepped with the epoch's validation loss (:153,279), the train loop (:178-242: forward with
 o_type=task, CrossEntropy, accuracy, loss all-reduce for the meter, zero_grad/backward/step, the print columns, the TSV row),
 the validation loop under model.eval() + no_grad (:245-310) with the best-accuracy checkpoint ``save_{epoch}_max.pth``
-replacing the previous best, and the side-stream data_prefetcher (:313-352).
+replacing the previous best, and the side-stream host-to-HBM batch overlap (:313-352; cstp_amd.device_batches).
 What differs (each a fix of something that cannot work in the reference, none changes the arithmetic):
   * ``--task scratch`` forwards with o_type 'ft_all' (the reference passes o_type='scratch', which R21DBYOL.forward
     rejects, r21d_byol.py:400-401); ``--task resume`` continues an ft_all run (undefined model in the reference);
@@ -35,10 +35,10 @@ from cstp_amd import ops
 from cstp_amd.model import generate_model
 from cstp_amd.optim import build_optimizer
 from cstp_amd.opts import parse_opts
-from cstp_amd.prefetch import data_prefetcher
+from cstp_amd.device_batches import DeviceBatches
 from cstp_amd.scheduler import ReduceLROnPlateau
 from cstp_amd.synthetic import SyntheticLabelledClips
-from cstp_amd.train import FineTuneStep
+from cstp_amd.train import FineTuneStep, sync_buffers
 from cstp_amd.utils import AverageMeter, Logger, calculate_accuracy, get_dataloader
 
 TRAIN_TASKS = ("ft_fc", "ft_all", "scratch", "resume")
@@ -70,10 +70,8 @@ def train(epoch, train_dataloader, step_fn, optimizer, opts, train_logger, len_t
     batch_time, data_time, losses, accuracies = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     end_time = time.time()
     n_iter = int(len_train_data / opts.batch_size)
-    prefetcher = data_prefetcher(train_dataloader, opts)
-    inputs, targets = prefetcher.next()
     i = 0
-    while inputs is not None:
+    for inputs, targets in DeviceBatches(train_dataloader, opts.device):
         i += 1
         data_time.update(time.time() - end_time)
         loss, outputs = step_fn(inputs, targets)
@@ -94,7 +92,6 @@ def train(epoch, train_dataloader, step_fn, optimizer, opts, train_logger, len_t
                                         left=(batch_time.avg * ((opts.n_epochs - epoch) * n_iter + n_iter - i)) / 3600 / 24))
         if opts.max_steps and i >= opts.max_steps:
             break
-        inputs, targets = prefetcher.next()
     if opts.rank == 0 and opts.local_rank == 0:
         train_logger.log({"epoch": epoch, "loss": losses.avg, "acc": accuracies.avg,
                           "lr": float("{:.5f}".format(optimizer.param_groups[-1]["lr"]))})
@@ -106,11 +103,12 @@ def validation(epoch, val_dataloader, model, optimizer, opts, val_logger, len_va
     o_type = o_type_for(opts.task)
     n_iter = int(len_val_data / opts.batch_size)
     model.eval()     # BatchNorm switches to its running statistics (cstp_bn_forward_eval)
+    # DDP(broadcast_buffers=True) hands rank 0's running statistics to every rank at the first eval forward too
+    # (models/model.py:97-103): every rank validates -- and rank 0 checkpoints -- the same statistics
+    sync_buffers(model)
     with torch.no_grad():
-        prefetcher = data_prefetcher(val_dataloader, opts)
-        inputs, targets = prefetcher.next()
         i = 0
-        while inputs is not None:
+        for inputs, targets in DeviceBatches(val_dataloader, opts.device):
             end_time = time.time()
             outputs = model(inputs, o_type=o_type)
             loss = ops.cross_entropy(outputs, targets)
@@ -125,7 +123,6 @@ def validation(epoch, val_dataloader, model, optimizer, opts, val_logger, len_va
                   "Acc {acc.val:.3f} ({acc.avg:.3f})".format(epoch, i + 1, n_iter, batch_time=batch_time,
                                                              data_time=data_time, loss=losses, acc=accuracies))
             i += 1
-            inputs, targets = prefetcher.next()
     # every rank sees the same plateau metric and takes the same lr decision (see the module docstring)
     val_loss = losses.avg
     if opts.distributed:

@@ -264,3 +264,43 @@ def test_get_dataloader_shards_across_ranks():
         get_dataloader(ds, o2, "byol")
         assert o2.batch_size == 4                                                    # utils.py:98 overwrites it
     assert seen[0].isdisjoint(seen[1]) and len(seen[0] | seen[1]) == 22
+
+
+def test_optimizer_keeps_frozen_tensors_in_the_torch_index_space():
+    """main_byol.py:228 builds optim.SGD(model.parameters()) over [online | TARGET (requires_grad False) | predictor |
+    heads]: the frozen target tensors occupy param_groups / state indices although they never get state.  A checkpoint
+    written here must load into torch.optim.SGD built over the same list (the reference's resume) with predictor / head
+    momentum at the reference's indices, and a reference checkpoint must load back."""
+    from cstp_amd.optim import FlatSGD
+    sizes = [(3, 5), (6,), (2, 2, 3), (4,)]
+    arena, trainable, offs = _cpu_arena_params(sizes)
+    frozen = [torch.nn.Parameter(torch.randn(3, 5), requires_grad=False), torch.nn.Parameter(torch.randn(6), requires_grad=False)]
+    # model.parameters() order: online (2 tensors), target (2, frozen, outside the arena), predictor + head (2)
+    plist = trainable[:2] + frozen + trainable[2:]
+    opt = FlatSGD(plist, lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=arena)
+    assert len(opt.param_groups[0]["params"]) == 6
+    opt._buf.copy_(torch.arange(opt._buf.numel(), dtype=torch.float32) + 1.0)
+    opt._steps = 1
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["params"] == [0, 1, 2, 3, 4, 5] and sorted(sd["state"]) == [0, 1, 4, 5]
+    clones = [torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for p in plist]
+    ref = torch.optim.SGD(clones, lr=1.0, momentum=0.0)
+    ref.load_state_dict(sd)                                 # raises on a param-count mismatch
+    for idx, ti in ((0, 0), (1, 1), (4, 2), (5, 3)):
+        n = int(np.prod(sizes[ti]))
+        assert torch.equal(ref.state[clones[idx]]["momentum_buffer"], opt._buf[offs[ti]:offs[ti] + n].view(sizes[ti]))
+    assert clones[2] not in ref.state and clones[3] not in ref.state
+    for c in clones:
+        if c.requires_grad:
+            c.grad = torch.ones_like(c)
+    ref.step()
+    back = FlatSGD(plist, lr=0.1, momentum=0.0, arenas=arena)
+    back.load_state_dict(ref.state_dict())
+    for idx, ti in ((0, 0), (1, 1), (4, 2), (5, 3)):
+        n = int(np.prod(sizes[ti]))
+        assert torch.equal(back._buf[offs[ti]:offs[ti] + n].view(sizes[ti]), ref.state[clones[idx]]["momentum_buffer"])
+    # the launch plan covers the trainable arena as ONE run and never touches the frozen tensors
+    assert [(o, n) for o, n, _, _ in back._plan()] == [(0, arena["param"].numel())]
+    # a trainable tensor outside the arena is still an error
+    with pytest.raises(ValueError):
+        FlatSGD(trainable + [torch.nn.Parameter(torch.zeros(3))], lr=0.1, arenas=arena)
