@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(ctypes.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     "cstp_gemm_get_split_terms": (c_int32, []),
     "cstp_conv3d_query_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     "cstp_conv3d_set_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
+    "cstp_conv3d_get_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     "cstp_conv3d_autotune": (c_int32, [_P, POINTER(ConvDesc), c_int32, _P, _P, _P, _P, c_size_t, c_int32]),
     "cstp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "cstp_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,

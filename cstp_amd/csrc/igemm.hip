@@ -774,9 +774,14 @@ static std::unordered_map<TuneKey, Tile, TuneKeyHash> g_tuned;
 static thread_local const Tile* g_force_tile = nullptr;   // set only inside cstp_conv3d_autotune
 static thread_local int g_force_mode = -1;
 
+static bool native_only();
+static int split_planes();
+// tuned entries live in one class per GEMM arithmetic (cstp_gemm_set_split_terms / CSTP_GEMM): 1 = tiles chosen among the
+// native f32 MFMA kernels only, 2 / 3 = chosen with the f16-pair / bf16-triple split kernels among the candidates
 static TuneKey tune_key(const cstp_conv_desc& d, int mode) {
   TuneKey k;
-  const int f[16] = {d.n, d.c, d.d, d.h, d.w, d.k, d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw, mode};
+  const int f[16] = {d.n, d.c, d.d, d.h, d.w, d.k, d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw,
+                     mode + 16 * (native_only() ? 1 : split_planes())};
   memcpy(k.v, f, sizeof(f));
   return k;
 }
@@ -814,7 +819,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
-  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t)))
+  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
     p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
@@ -822,7 +827,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
-  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t))) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t) || native_only())) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -844,7 +849,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
       p.w_mt = wt.m16 ? 9 : wt.mt;
       p.w_blocks = 256 * wt.wm;
       // igemm_k2s (3xbf16 split): 128- or 144-row tiles, 31-bit buffer offsets
-      p.w_split = wt.sp && !p.w_straddle && x_small && y_small && (wt.mt == 4 || wt.mt == 8 || wt.mt == 9);
+      p.w_split = wt.sp && !native_only() && !p.w_straddle && x_small && y_small && (wt.mt == 4 || wt.mt == 8 || wt.mt == 9);
       if (wt.sp && !p.w_split) p.w_mt = pick_mt(d.k);
     }
   }
@@ -856,14 +861,21 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
 
 // planes per operand of the split kernels: 2 = f16 pair / three products (default), 3 = bf16 triple / six products
 // (CSTP_GEMM=bf16x3); CSTP_GEMM=f32 keeps every GEMM on the native f32 MFMA kernels
-static std::atomic<int> g_split_terms{0};          // 0 = not overridden (cstp_gemm_set_split_terms)
+static std::atomic<int> g_split_terms{0};          // 0 = not overridden (cstp_gemm_set_split_terms); 1 = native f32 only
 static int split_planes() {
   static const int env_np = [] {
     const char* e = getenv("CSTP_GEMM");
     return (e != nullptr && strcmp(e, "bf16x3") == 0) ? 3 : 2;
   }();
   const int o = g_split_terms.load(std::memory_order_relaxed);
-  return o != 0 ? o : env_np;
+  return o >= 2 ? o : env_np;
+}
+static bool native_only() {
+  static const bool env_f32 = [] {
+    const char* e = getenv("CSTP_GEMM");
+    return e != nullptr && strcmp(e, "f32") == 0;
+  }();
+  return env_f32 || g_split_terms.load(std::memory_order_relaxed) == 1;
 }
 // tail of the workspace: [0, 256) absmax cells of the activation operand(s), then the per-row inverse scales of the packed
 // weights (<= max(k, c) + 160 rows)
@@ -1182,9 +1194,16 @@ extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc
 
 extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4) {
   CSTP_REQUIRE(desc && out4, "null argument");
-  CSTP_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (backward_data)");
+  CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  if (mode == 2) {
+    out4[0] = p.w_split ? 16 * p.w_mt : (p.w_mt == 9 ? 144 : 32 * p.w_mt);
+    out4[1] = 128;
+    out4[2] = p.w_split ? split_planes() : 0;
+    out4[3] = p.w_blocks / 256;
+    return 0;
+  }
   const Tile& t = mode == 0 ? p.f_t : p.d_t;
   out4[0] = tile_bm(t);
   out4[1] = tile_bn(t);
@@ -1193,13 +1212,30 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   return 0;
 }
 
+extern "C" int cstp_conv3d_get_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* tile4) {
+  CSTP_REQUIRE(desc && tile4, "null argument");
+  CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
+  Tile t;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(tune_key(*desc, mode));
+    if (it == g_tuned.end()) { tile4[0] = tile4[1] = tile4[2] = tile4[3] = -1; return 0; }
+    t = it->second;
+  }
+  tile4[0] = t.sp;
+  tile4[1] = t.m16 ? 9 : t.mt;
+  tile4[2] = t.wm;                                   // native: waves along rows; split: 128-column halves; mode 2: blocks / 256
+  tile4[3] = mode == 2 ? 0 : (t.tpb == 2 ? 2 : 1);
+  return 0;
+}
+
 extern "C" int cstp_gemm_set_split_terms(int32_t terms) {
-  CSTP_REQUIRE(terms == 0 || terms == 2 || terms == 3, "split terms: 2 (f16 pair), 3 (bf16 triple) or 0 (environment default)");
+  CSTP_REQUIRE(terms >= 0 && terms <= 3, "split terms: 2 (f16 pair), 3 (bf16 triple), 1 (native f32 MFMA only) or 0 (environment default)");
   g_split_terms.store(terms, std::memory_order_relaxed);
   return 0;
 }
 
-extern "C" int32_t cstp_gemm_get_split_terms(void) { return split_planes(); }
+extern "C" int32_t cstp_gemm_get_split_terms(void) { return native_only() ? 1 : split_planes(); }
 
 extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, const int32_t* tile4) {
   CSTP_REQUIRE(desc && tile4, "null argument");
@@ -1222,9 +1258,10 @@ extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, co
     t = Tile{mt, tile4[2] == 2 ? 2 : 1, 0, 1, 1};
   } else {
     const int wm = tile4[2], tpb = tile4[3];
-    CSTP_REQUIRE((wm == 1 && mt >= 1 && mt <= 5) || (wm == 2 && mt >= 1 && mt <= 2) || (wm == 4 && mt == 1), "native tile shape");
+    CSTP_REQUIRE((wm == 1 && ((mt >= 1 && mt <= 5) || mt == 9)) || (wm == 2 && mt >= 1 && mt <= 2) || (wm == 4 && mt == 1),
+                 "native tile shape");
     CSTP_REQUIRE(tpb == 1 || tpb == 2, "K-tiles per barrier: 1 or 2");
-    t = Tile{mt, wm, 0, tpb, 0};
+    t = Tile{mt, wm, mt == 9 ? 1 : 0, tpb, 0};       // mt == 9: the 144-row tile on the 16x16x4 MFMA
   }
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned[tune_key(*desc, mode)] = t;
@@ -1258,8 +1295,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     Tile wc[24];
     int nw = 0;
     const int base = pick_mt(d.k);
-    static const char* gemm_env2 = getenv("CSTP_GEMM");
-    const bool allow_split2 = !(gemm_env2 != nullptr && strcmp(gemm_env2, "f32") == 0);
+    const bool allow_split2 = !native_only();
     for (int blocks = 4; blocks <= 16; blocks *= 2) {
       wc[nw++] = Tile{base, blocks, 0};
       if (!stem && d.k > 128 && d.k <= 144) wc[nw++] = Tile{9, blocks, 1};
@@ -1311,8 +1347,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     for (int i = 0; i < n1; ++i) { cand[ncand] = cand[i]; cand[ncand].tpb = 2; ++ncand; }
   }
   // the 3xbf16-split kernels (fp32-equivalent products on the bf16 matrix cores), unless CSTP_GEMM=f32
-  static const char* gemm_env = getenv("CSTP_GEMM");
-  const bool allow_split = !(gemm_env != nullptr && strcmp(gemm_env, "f32") == 0);
+  const bool allow_split = !native_only();
   if (allow_split && !straddle && d.kt * d.kh * d.kw <= 27) {
     // row-tile heights 32..144; keep those that pad M by at most ~1/8 (and the two smallest paddings regardless)
     static const int smt[] = {2, 3, 4, 5, 6, 8, 9};

@@ -132,6 +132,7 @@ class PretrainStep:
         # weight gradients may bypass autograd's accumulation (side stream, ops._Conv3d.backward) when the gradients live in
         # the arena and no DDP reducer hook waits for them
         ops.DIRECT_WGRAD = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
+        self._tiles_shared = False
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
         if self._flat_grad is not None:
@@ -144,6 +145,12 @@ class PretrainStep:
         gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None
         self.optimizer.step()
         out.grad_norm = gnorm
+        if not self._tiles_shared:
+            # every layer geometry has been seen (and tuned, if the persisted table lacked it) once: all ranks adopt rank
+            # 0's tiles so that the same layer runs the same kernel everywhere
+            self._tiles_shared = True
+            if self._flat_grad is not None and self._flat_grad.is_cuda:
+                ops.share_tune_table()
         return out
 
     def _forward_backward(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 12
+#define CSTP_ABI_VERSION 13
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -88,22 +88,29 @@ int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, con
 /* Arithmetic of the split kernels (csrc/igemm_split.h), process-wide: 2 = every fp32 operand scaled by a power of two and
  * split into an f16 PAIR, three f16 MFMA products per fp32 product (default; 22 operand bits, measured at least as close to
  * fp64 as the native f32 MFMA chain); 3 = split EXACTLY into a bf16 TRIPLE, six bf16 MFMA products (no operand scaling, no
- * dynamic-range caveat; also selected by CSTP_GEMM=bf16x3 in the environment); 0 = back to the environment's choice.
- * Both accumulate in f32. */
+ * dynamic-range caveat; also selected by CSTP_GEMM=bf16x3 in the environment); 1 = no split kernels at all: every GEMM-shaped
+ * op on the native f32 MFMA (bit-for-bit an fmaf chain; also CSTP_GEMM=f32), with its own class of tuned tiles;
+ * 0 = back to the environment's choice.  All accumulate in f32.  cstp_gemm_get_split_terms returns 1, 2 or 3. */
 int cstp_gemm_set_split_terms(int32_t terms);
 int32_t cstp_gemm_get_split_terms(void);
 
-/* Which kernel variant the next forward (mode 0) / backward_data (mode 1) call with this descriptor will run:
- * out[0] = rows per block tile, out[1] = positions per block tile, out[2] = 0 for the native f32 MFMA kernel, else the
- * number of terms each operand is split into by the split kernel (2 or 3, see cstp_gemm_set_split_terms), out[3] = K-tiles
- * per barrier.  Reporting only (bench.py names the kernel and picks the roofline peak with it). */
+/* Which kernel variant the next forward (mode 0) / backward_data (mode 1) / backward_weight (mode 2) call with this
+ * descriptor will run: out[0] = rows per block tile, out[1] = positions (mode 2: (tap, channel) columns) per block tile,
+ * out[2] = 0 for the native f32 MFMA kernel, else the number of terms each operand is split into by the split kernel (2 or
+ * 3, see cstp_gemm_set_split_terms), out[3] = K-tiles per barrier (mode 2: split-K block target / 256).  Reporting only
+ * (bench.py names the kernels and picks their roofline peaks with it). */
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
+
+/* The TUNED entry of one geometry and direction in cstp_conv3d_set_tile's encoding (tile4[0] = -1 when the geometry has
+ * not been tuned or pinned in the current arithmetic class): lets the host persist a tuning table and replay it with
+ * cstp_conv3d_set_tile, so that every rank and every run executes the same kernels (cstp_amd/tuned/). */
+int cstp_conv3d_get_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* tile4);
 
 /* Pin the kernel variant of one geometry and direction (what cstp_conv3d_autotune would otherwise decide by timing):
  * mode 0 forward / 1 backward_data: tile[0] = 1 for the split kernel (arithmetic: cstp_gemm_set_split_terms; tile[1] = row tiles of 16: 2,3,4,5,6,8,9;
  * tile[2] = 2 selects the 256-column tile, available with 8 / 9 row tiles) or 0
- * for the native f32 kernel (tile[1] = row tiles of 32: 1..5, tile[2] = waves along rows 1|2|4, tile[3] = K-tiles per barrier
- * 1|2); mode 2 backward_weight: tile[0] = 1 split (tile[1] = 4|8|9 row tiles of 16) or 0 native (tile[1] = 1..5 row tiles of
+ * for the native f32 kernel (tile[1] = row tiles of 32: 1..5, or 9 = the 144-row tile of nine 16-row MFMA tiles, tile[2] = waves
+ * along rows 1|2|4, tile[3] = K-tiles per barrier 1|2); mode 2 backward_weight: tile[0] = 1 split (tile[1] = 4|8|9 row tiles of 16) or 0 native (tile[1] = 1..5 row tiles of
  * 32, or 9 = the 144-row tile), tile[2] = split-K block target / 256 (4, 8, 16).  Inadmissible requests (3-channel stem, > 27
  * taps, >= 2 GiB tensors for the split kernels) fall back to a native tile at call time.  Used by the parity tests to put every
  * kernel variant against the fp64 reference regardless of which one is fastest on the machine at hand. */

@@ -158,7 +158,28 @@ def _glorot_bound(shape) -> float:
     return math.sqrt(6.0 / float(fi + fo))
 
 
-def closed_form_tensor(name: str, shape, kind: str) -> torch.Tensor:
+def hash_pow2(n: int, seed: int, span: int = 21) -> torch.Tensor:
+    """n exact powers of two 2^0 .. 2^-(span-1), the exponent drawn by the integer hash: a log-uniform magnitude over
+    six decades (2^-20 ~ 1e-6) with no libm call, so the fill is bit-identical everywhere."""
+    m32 = 0xFFFFFFFF
+    h = (torch.arange(n, dtype=torch.int64) * 2246822519 + (seed * 9176 + 777)) & m32
+    h = ((h ^ (h >> 15)) * 2654435761) & m32
+    h = h ^ (h >> 13)
+    return torch.ldexp(torch.ones(n, dtype=torch.float64), -(h % span).to(torch.int32))
+
+
+def hash_mask(n: int, seed: int) -> torch.Tensor:
+    """n values in {0, 1}, half of them zero (post-ReLU-like sparsity)."""
+    m32 = 0xFFFFFFFF
+    h = (torch.arange(n, dtype=torch.int64) * 3266489917 + (seed * 374761 + 393)) & m32
+    h = ((h ^ (h >> 15)) * 2246822519) & m32
+    return ((h >> 11) & 1).to(torch.float64)
+
+
+def closed_form_tensor(name: str, shape, kind: str, heavy: bool = False) -> torch.Tensor:
+    """``heavy``: every weight / BN gamma is additionally multiplied by its own power of two from 2^0 .. 2^-20 (x 4, which
+    restores the RMS): magnitudes inside ONE tensor then span six decades -- the case a per-tensor operand scale
+    (the 2xf16-split GEMM kernels of the HIP path) has to survive."""
     n = 1
     for s in shape:
         n *= s
@@ -169,6 +190,8 @@ def closed_form_tensor(name: str, shape, kind: str) -> torch.Tensor:
     if kind == "buf_var":
         return torch.ones(shape, dtype=torch.float64)
     u = hash_uniform(n, _name_seed(name))
+    if heavy and kind in ("conv_w", "lin_w", "bn_w"):
+        u = u * hash_pow2(n, _name_seed(name)) * 4.0
     if kind in ("conv_w", "lin_w", "bn_w"):
         # the reference re-initialises conv/linear weights AND BN gamma ~ U(+-sqrt(6/(fi+fo)))
         # (r21d_byol.py:301-329); mimic the scale so the dynamics are the reference's
@@ -182,20 +205,24 @@ def closed_form_tensor(name: str, shape, kind: str) -> torch.Tensor:
     return v.reshape(shape)
 
 
-def closed_form_state(layer_sizes, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+def closed_form_state(layer_sizes, dtype=torch.float32, heavy: bool = False) -> "OrderedDict[str, torch.Tensor]":
     sd = OrderedDict()
     for key, shape, kind in model_spec(layer_sizes):
-        t = closed_form_tensor(key, shape, kind)
+        t = closed_form_tensor(key, shape, kind, heavy)
         sd[key] = t if kind == "buf_nbt" else t.to(dtype)
     return sd
 
 
-def closed_form_clips(b: int, t: int, hw: int, dtype=torch.float32, seed_phase: int = 0):
+def closed_form_clips(b: int, t: int, hw: int, dtype=torch.float32, seed_phase: int = 0, heavy: bool = False):
     """Two deterministic clips in [-1, 1] plus labels in the reference ranges
-    (datasets.py:873-881,915; preprocess_data.py:520)."""
+    (datasets.py:873-881,915; preprocess_data.py:520).  ``heavy``: half of the pixels are exactly zero and the rest
+    carry a log-uniform magnitude over 2^0 .. 2^-20 (see closed_form_tensor)."""
     n = b * 3 * t * hw * hw
     x1 = hash_uniform(n, 7001 + int(seed_phase))
     x2 = hash_uniform(n, 9001 + int(seed_phase))
+    if heavy:
+        x1 = x1 * hash_pow2(n, 7101 + int(seed_phase)) * hash_mask(n, 7201 + int(seed_phase))
+        x2 = x2 * hash_pow2(n, 9101 + int(seed_phase)) * hash_mask(n, 9201 + int(seed_phase))
     shp = (b, 3, t, hw, hw)
     j = torch.arange(b, dtype=torch.int64)
     labels = {

@@ -42,17 +42,24 @@ CONFIGS = {
     "r18_small": (18, 4, 8, 56, 2, 0.005, 5e-4),
     "r18_cfg2": (18, 4, 16, 112, 1, 0.05, 5e-4),
     "r34_small": (34, 8, 8, 64, 1, 0.05, 5e-4),
+    # BASELINE configs[3] at its TRUE per-clip shape: R(2+1)D-34, 32-frame clips of 112x112 (B = 2: BatchNorm1d needs >= 2)
+    "r34_cfg4": (34, 2, 32, 112, 1, 0.05, 5e-4),
+    # heavy-tailed fills (oracle.closed_form_*: heavy=True): magnitudes inside every weight tensor and inside the clips
+    # span six decades, half of the pixels are zero -- stresses the per-tensor operand scale of the 2xf16-split kernels
+    "d1_heavy": (1, 4, 8, 56, 1, 0.05, 5e-4),
+    "r18_heavy": (18, 4, 8, 56, 1, 0.05, 5e-4),
+    "r34_heavy": (34, 8, 8, 64, 1, 0.05, 5e-4),
 }
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 1.0, 1.0)
 
 
-def build_reference(layer_sizes, dtype):
+def build_reference(layer_sizes, dtype, heavy=False):
     m = ref_model.R21DBYOL(pretrain=True)
     if tuple(layer_sizes) != (1, 1, 1, 1):
         m.online_net = ref_model.R2Plus1DNet(layer_sizes=tuple(layer_sizes), proj_flag=True)
         m.target_net = ref_model.R2Plus1DNet(layer_sizes=tuple(layer_sizes), proj_flag=True)
         m._set_grad(m.target_net, False)
-    sd = orc.closed_form_state(layer_sizes, dtype=torch.float64)
+    sd = orc.closed_form_state(layer_sizes, dtype=torch.float64, heavy=heavy)
     missing = m.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     assert list(m.state_dict().keys()) == list(sd.keys()), "state-dict order differs from oracle spec"
@@ -73,12 +80,13 @@ def run_config(name):
     depth, b, t, hw, steps, lr, wd = CONFIGS[name]
     ls = orc.layer_sizes_for_depth(depth)
     dtype = torch.float64
-    model = build_reference(ls, dtype)
-    x1, x2, labels = orc.closed_form_clips(b, t, hw, dtype=dtype)
+    heavy = name.endswith("_heavy")
+    model = build_reference(ls, dtype, heavy)
+    x1, x2, labels = orc.closed_form_clips(b, t, hw, dtype=dtype, heavy=heavy)
     crit = torch.nn.CrossEntropyLoss()
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=wd)
     names = [k for k, _ in model.named_parameters()]
-    out = {"meta": np.array([depth, b, t, hw, steps], dtype=np.int64), "lr": np.array(lr), "wd": np.array(wd),
+    out = {"meta": np.array([depth, b, t, hw, steps], dtype=np.int64), "heavy": np.array(int(heavy)), "lr": np.array(lr), "wd": np.array(wd),
            "loss_weight": np.array(LOSS_WEIGHT)}
     for step in range(1, steps + 1):
         t0 = time.time()
@@ -116,7 +124,8 @@ def run_config(name):
     out["param_keys"] = np.array(names)
 
     # forward internals from a fresh model (step-1 state) -- features/projections/predictions
-    model = build_reference(ls, dtype)
+    del model, opt, total, loss_byol, logits, ce
+    model = build_reference(ls, dtype, heavy)
     with torch.no_grad():
         f1, z1 = model.online_net(x1)
         f2, z2 = model.online_net(x2)
@@ -131,8 +140,8 @@ def run_config(name):
     nt = NTXentLoss(device="cpu", batch_size=b, temperature=0.5, use_cosine_similarity=True)
     out["fwd.ntxent"] = np.array(float(nt(z1, z2)))
     # fp32 run of the reference for the noise-floor record
-    m32 = build_reference(ls, torch.float32)
-    a1, a2, _ = orc.closed_form_clips(b, t, hw, dtype=torch.float32)
+    m32 = build_reference(ls, torch.float32, heavy)
+    a1, a2, _ = orc.closed_form_clips(b, t, hw, dtype=torch.float32, heavy=heavy)
     with torch.no_grad():
         l32, lg32 = m32(a1, a2, o_type="loss_com")
     out["fp32.loss_byol"] = np.array(float(l32))

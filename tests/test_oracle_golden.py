@@ -22,11 +22,14 @@ TOLS = {1: (1e-4, 2e-2), 2: (3e-2, 2e-1), 3: (5e-2, 5e-1)}
 TOL = TOLS[1][0]
 # R(2+1)D-34 (33 conv+BN layers): stock PyTorch fp32 itself sits 0.9e-4 from the fp64 truth on the
 # projector outputs of r34_small, so that fixture's output bar is 3e-4 for every implementation.
-OUT_SCALE = {"r34_small": 3.0}
+# (The same holds for the other R(2+1)D-34 fixtures: r34_heavy, and r34_cfg4 = BASELINE configs[3]'s true clip shape.)
+OUT_SCALE = {"r34_small": 3.0, "r34_heavy": 3.0, "r34_cfg4": 3.0}
 # ... and its per-tensor gradient / momentum checksums (66 train-mode BN layers over a batch of 8) sit 1.3e-2 (stock PyTorch
 # fp32), 1.5e-2..2.03e-2 (the HIP kernels, depending on the tile the autotuner picks -- each kernel variant is 4e-7 rms from
 # fp64 per convolution, tools/split_accuracy.py) from the fp64 truth: noise amplification, not arithmetic.  3e-2 for that fixture.
-GRAD_SCALE = {"r34_small": 1.5}
+# r34_heavy (six-decade magnitudes inside every weight tensor): stock PyTorch fp32 -- this oracle -- sits 3.2e-2 from the fp64
+# truth on the momentum checksums (outputs: 3e-5), so 5e-2 there.
+GRAD_SCALE = {"r34_small": 1.5, "r34_heavy": 2.5, "r34_cfg4": 1.5}
 # post-step parameter checksums carry lr x (gradient noise): 2e-3 at step 1 (lr up to 0.05)
 STATE_TOLS = {1: 2e-3, 2: 3e-2, 3: 5e-2}
 
@@ -55,13 +58,18 @@ def state_checksums(sd, keys):
     return np.array(out)
 
 
+def is_heavy(g):
+    """fixtures written since round 2 say whether their closed-form fills are the heavy-tailed ones"""
+    return bool(int(g["heavy"])) if "heavy" in g.files else False
+
+
 def run_oracle(name, steps=None):
     g = load(name)
     depth, b, t, hw, nsteps = [int(v) for v in g["meta"]]
     nsteps = steps or nsteps
     ls = orc.layer_sizes_for_depth(depth)
-    sd = orc.closed_form_state(ls, torch.float32)
-    x1, x2, labels = orc.closed_form_clips(b, t, hw, torch.float32)
+    sd = orc.closed_form_state(ls, torch.float32, heavy=is_heavy(g))
+    x1, x2, labels = orc.closed_form_clips(b, t, hw, torch.float32, heavy=is_heavy(g))
     mom, infos, states, moms = {}, [], [], []
     keys = [str(k) for k in g["state_keys"]]
     pkeys = [str(k) for k in g["param_keys"]]
@@ -74,7 +82,8 @@ def run_oracle(name, steps=None):
     return g, infos, states, moms, pkeys
 
 
-@pytest.mark.parametrize("name", ["d1_small", "r18_small", "r34_small", "d1_cfg1"])
+@pytest.mark.parametrize("name", ["d1_small", "r18_small", "r34_small", "d1_cfg1", "d1_heavy", "r18_heavy", "r34_heavy",
+                                  "r34_cfg4"])
 def test_oracle_matches_reference_golden(name):
     g, infos, states, moms, pkeys = run_oracle(name)
     for s, info in enumerate(infos, start=1):
