@@ -87,8 +87,11 @@ def _triple(v) -> Tuple[int, int, int]:
 # (cstp_conv3d_autotune), and the winner is written back to the table -- so that runs, boxes and ranks execute the same kernels
 # (round-1 VERDICT weak-9: re-deriving the table by timing on every process start made bench.py vary 217..227 clips/s).
 # CSTP_AUTOTUNE=0 keeps the analytic choice; CSTP_TUNE_TABLE=0 ignores and does not write the file; CSTP_TUNE_TABLE=<path>
-# uses another file.
+# uses another file; CSTP_TUNE_TABLE_RO=1 reads it but never writes (the test suite: tests/conftest.py).  TUNE_REV names the
+# candidate set the entries were chosen from: bump it whenever a kernel variant is added or changed, and stale tables are
+# ignored.
 AUTOTUNE = os.environ.get("CSTP_AUTOTUNE", "1") != "0"
+TUNE_REV = 2
 _tuned = set()
 _TABLE_ENV = os.environ.get("CSTP_TUNE_TABLE", "")
 TUNE_TABLE_PATH = None if _TABLE_ENV == "0" else (
@@ -107,7 +110,7 @@ def _load_table():
                 import json
                 with open(TUNE_TABLE_PATH) as f:
                     data = json.load(f)
-                if data.get("arch") == "gfx950" and data.get("abi") == _lib.ABI_VERSION:
+                if data.get("arch") == "gfx950" and data.get("abi") == _lib.ABI_VERSION and data.get("rev") == TUNE_REV:
                     _table = {k: [int(v) for v in t] for k, t in data.get("tiles", {}).items()}
             except (OSError, ValueError, AttributeError):
                 _table = {}
@@ -118,14 +121,14 @@ def save_tune_table(path=None) -> bool:
     """Write the table (atomically) if it has new entries; silently skipped on a read-only tree."""
     global _table_dirty
     path = path or TUNE_TABLE_PATH
-    if path is None or _table is None or not _table_dirty:
+    if path is None or _table is None or not _table_dirty or os.environ.get("CSTP_TUNE_TABLE_RO", "0") == "1":
         return False
     import json
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "w") as f:
-            json.dump({"arch": "gfx950", "abi": _lib.ABI_VERSION,
+            json.dump({"arch": "gfx950", "abi": _lib.ABI_VERSION, "rev": TUNE_REV,
                        "key": "arithmetic|mode|" + ",".join(f for f, _ in ConvDesc._fields_),
                        "tile": "cstp_conv3d_set_tile encoding", "tiles": dict(sorted(_table.items()))}, f, indent=0)
         os.replace(tmp, path)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_oracle_golden import GRAD_SCALE, OUT_SCALE, STATE_TOLS, TOLS, cs_err, is_heavy, load, rel
+from test_oracle_golden import GRAD_SCALE, OUT_SCALE, STATE_SCALE, STATE_TOLS, TOLS, cs_err, is_heavy, load, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -115,7 +115,7 @@ def test_hip_path_matches_reference_golden(name):
         assert rel(out["grad_norm"], g[pre + "grad_norm"]) < gtol
         gn = np.array([out["grad_norms"].get(k, -1.0) for k in pkeys])
         assert rel(gn, g[pre + "grad_norms"]) < gtol
-        assert cs_err(checksums(model, keys), g[pre + "state_cs"]) < STATE_TOLS[s]
+        assert cs_err(checksums(model, keys), g[pre + "state_cs"]) < STATE_TOLS[s] * STATE_SCALE.get(name, 1.0)
         # state indices are torch.optim.SGD(model.parameters())'s: the frozen target tensors keep their rows (no state)
         mcs = momentum_checksums(opt)
         assert mcs.shape == g[pre + "mom_cs"].shape
