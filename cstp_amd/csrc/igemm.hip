@@ -702,6 +702,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 // ------------------------------------------------------------------------------------------
 }  // namespace cstp
 #include "igemm_split.h"
+#include "igemm_patch.h"
 namespace cstp {
 
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
@@ -715,10 +716,23 @@ static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, m
   return best;
 }
 
-// sp = 1: the 3xbf16-split kernel igemm_k1s (igemm_split.h), tile (16*mt) x 128, 512 threads
+// sp = 1: the split kernels igemm_k1s (igemm_split.h), tile (16*mt) x 128, 512 threads
+// sp = 2: the LDS-resident-patch kernel igemm_k1p (igemm_patch.h), tile (16*mt) x 224, stride-1 1x3x3 layers, f16 pair only
 struct Tile { int mt, wm, m16, tpb, sp; };   // tpb: 0/1 = one K-tile per barrier, 2 = two
 static inline int tile_bm(const Tile& t) { return (t.m16 || t.sp) ? 16 * t.mt : 32 * t.mt * t.wm; }
-static inline int tile_bn(const Tile& t) { return t.sp ? (t.wm == 2 ? 256 : 128) : 32 * (4 / t.wm); }   // split: wm = 128-column halves
+static inline int tile_bn(const Tile& t) {   // split: wm = 128-column halves
+  return t.sp == 2 ? KP_NPOS : t.sp ? (t.wm == 2 ? 256 : 128) : 32 * (4 / t.wm);
+}
+static inline bool patch_mt_ok(int mt) { return mt == 4 || mt == 8 || mt == 9; }
+static bool native_only();
+static int split_planes();
+// the patch kernel serves 1x3x3, stride 1, padding (0,1,1) in the f16-pair arithmetic, frames whose patch fits its LDS image
+static bool patch_geom_ok(const cstp_conv_desc& d) {
+  if (!(d.kt == 1 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 1 && d.pw == 1))
+    return false;
+  if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
+  return patch_rows_needed(d.n * d.d, d.h, d.w) <= KP_ROWS;
+}
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
 
@@ -774,8 +788,6 @@ static std::unordered_map<TuneKey, Tile, TuneKeyHash> g_tuned;
 static thread_local const Tile* g_force_tile = nullptr;   // set only inside cstp_conv3d_autotune
 static thread_local int g_force_mode = -1;
 
-static bool native_only();
-static int split_planes();
 // tuned entries live in one class per GEMM arithmetic (cstp_gemm_set_split_terms / CSTP_GEMM): 1 = tiles chosen among the
 // native f32 MFMA kernels only, 2 / 3 = chosen with the f16-pair / bf16-triple split kernels among the candidates
 static TuneKey tune_key(const cstp_conv_desc& d, int mode) {
@@ -819,7 +831,8 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
-  if (p.f_t.sp && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
+  if (p.f_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.f_t.mt) && patch_geom_ok(d))) p.f_t = Tile{2, 1, 0, 1, 0};
+  if (p.f_t.sp == 1 && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
     p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
@@ -827,7 +840,8 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
-  if (p.d_t.sp && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t) || native_only())) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.d_t.mt) && patch_geom_ok(d))) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp == 1 && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t) || native_only())) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
   p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -887,6 +901,12 @@ static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   // (heuristic or tuned later) fits the workspace the caller sized once
   // (the split kernels' packed operand is three bf16 planes = 6 bytes per element)
   size_t f = (size_t)p.f_Kp * ((size_t)d.k + 160) * 6, g = (size_t)p.d_Kp * ((size_t)d.c + 160) * 6;
+  // the patch kernel's packed operand: 32-channel blocks x 9 taps x (rows padded to <= 144) x 128 bytes
+  if (d.kt == 1 && d.kh == 3 && d.kw == 3) {
+    const size_t pf = (size_t)cdiv(d.c, 32) * 9 * ((size_t)d.k + 144) * 128, pg = (size_t)cdiv(d.k, 32) * 9 * ((size_t)d.c + 144) * 128;
+    if (pf > f) f = pf;
+    if (pg > g) g = pg;
+  }
   size_t w = (size_t)d.k * p.w_Jp * sizeof(float);
   size_t m = f > g ? f : g;
   if (w > m) m = w;
@@ -1004,6 +1024,33 @@ static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, con
                           src_absmax != nullptr ? src_absmax : cells);
 }
 
+// pack the weights for the patch kernel, make sure the gathered tensor's absmax cell is filled, launch it
+// (forward: src = x, Cs = c, M = k;  data gradient: src = dy, Cs = k, M = c -- a 3x3 stride-1 convolution with mirrored taps)
+static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
+                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax) {
+  PGeom g;
+  g.Cs = dgrad ? d.k : d.c;
+  g.ncb = cdiv(g.Cs, 32);
+  g.H = d.h; g.W = d.w; g.D = d.d; g.NF = d.n * d.d;
+  g.M = dgrad ? d.c : d.k;
+  g.rows_lds = patch_rows_needed(g.NF, g.H, g.W);
+  const int bm = 16 * tl.mt, nmblk = cdiv(g.M, bm);
+  const long P = (long)g.NF * g.H * g.W;
+  const int ntiles = (int)((P + KP_NPOS - 1) / KP_NPOS);
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
+  float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
+  hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nmblk * bm), dim3(256), 0, s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1,
+                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0);
+  const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
+  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
+  dim3 grid((unsigned)(8 * cdiv(ntiles, 8) * nmblk), 1, 1);
+#define CSTP_K1P(MT_) \
+  hipLaunchKernelGGL((igemm_k1p<MT_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk)
+  if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);
+#undef CSTP_K1P
+}
+
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
 struct InAffine { const float2* ss; int npg, groups, relu; };
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
@@ -1044,10 +1091,20 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
-  if (p.f_t.sp && in_affine != nullptr && in_affine->scale_shift != nullptr) {
+  if (p.f_t.sp != 0 && in_affine != nullptr && in_affine->scale_shift != nullptr) {
     // the split kernel has no fused input transform: such a call runs a native tile (and its operand padding)
     p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
     if (p.f_t.sp) p.f_t = Tile{2, 1, 0, 1, 0};
+    p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
+  }
+  if (p.f_t.sp == 2 && bias == nullptr) {
+    run_k1p(p.f_t, s, d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
+  if (p.f_t.sp == 2) {                               // (a bias rides only on the Linear layers: never a 3x3 geometry)
+    p.f_t = Tile{9, 1, 0, 1, 1};
+    if (!split_tile_ok(p.f_t) || p.f_straddle) p.f_t = Tile{2, 1, 0, 1, 0};
     p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
   }
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
@@ -1091,6 +1148,11 @@ extern "C" int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* 
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
+  if (p.d_t.sp == 2) {
+    run_k1p(p.d_t, s, d, true, w, dy, dx, ws, plan_main_bytes(d, p), dy_absmax);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t tot = (size_t)p.d_Kp * p.d_Mp;
   const bool d_split = p.d_t.sp != 0;
   if (!d_split)
@@ -1207,7 +1269,7 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   const Tile& t = mode == 0 ? p.f_t : p.d_t;
   out4[0] = tile_bm(t);
   out4[1] = tile_bn(t);
-  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? split_planes() : 0;
+  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? split_planes() : 0;       // (the patch kernel: f16 pair, 224 positions)
   out4[3] = t.tpb == 2 ? 2 : 1;
   return 0;
 }
@@ -1252,6 +1314,9 @@ extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, co
       CSTP_REQUIRE((mt >= 1 && mt <= 5) || mt == 9, "native weight-gradient tiles: 1..5 row tiles of 32, or 9 (144 rows)");
       t = Tile{mt, blocks, mt == 9 ? 1 : 0, 0, 0};
     }
+  } else if (split == 2) {
+    CSTP_REQUIRE(patch_mt_ok(mt), "patch tiles: 4, 8 or 9 row tiles of 16");
+    t = Tile{mt, 1, 0, 1, 2};
   } else if (split) {
     CSTP_REQUIRE(split_mt_ok(mt), "split tiles: 2, 3, 4, 5, 6, 8 or 9 row tiles of 16");
     CSTP_REQUIRE(tile4[2] == 0 || tile4[2] == 1 || (tile4[2] == 2 && mt >= 8), "split tiles: 128 columns, or 256 with 8 / 9 row tiles");
@@ -1339,7 +1404,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
   }
   const int M = mode == 0 ? d.k : d.c;
   const bool straddle = (mode == 0 && d.c < 8);
-  Tile cand[40] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
+  Tile cand[44] = {{1, 1, 0, 1}, {2, 1, 0, 1}, {3, 1, 0, 1}, {4, 1, 0, 1}, {5, 1, 0, 1}, {1, 2, 0, 1}, {2, 2, 0, 1}, {1, 4, 0, 1},
                    {9, 1, 1, 1}};
   int ncand = (CSTP_M16 && !straddle && M > 128 && M <= 144) ? 9 : 8;
   if (!straddle) {       // the same tiles with two K-tiles per barrier
@@ -1360,6 +1425,13 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
         if (mt >= 8) cand[ncand++] = Tile{mt, 2, 0, 1, 1};      // 256-column tile
       }
     }
+  }
+  if (allow_split && patch_geom_ok(d)) {       // the LDS-resident-patch kernel: row blocks of 64 / 128 / 144
+    static const int pmt[] = {4, 8, 9};
+    int best_pad = 1 << 30;
+    for (int mt : pmt) { const int pad = cdiv(M, 16 * mt) * 16 * mt - M; if (pad < best_pad) best_pad = pad; }
+    for (int mt : pmt)
+      if (cdiv(M, 16 * mt) * 16 * mt - M <= best_pad + M / 8 && ncand < 40) cand[ncand++] = Tile{mt, 1, 0, 1, 2};
   }
   hipStream_t s = as_stream(stream);
   hipEvent_t e0, e1;

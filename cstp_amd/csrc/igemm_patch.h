@@ -1,0 +1,378 @@
+// K1P  igemm_k1p<MT>: forward / data gradient of the stride-1 1x3x3 spatial convolutions with the INPUT PATCH RESIDENT IN LDS
+// (north_star: "LDS-staged input tiles"), f16-pair arithmetic (igemm_split.h: three v_mfma_f32_16x16x32_f16 per fp32 product).
+//
+// The gather kernels igemm_k1s fetch every activation element once per filter tap (x9) and re-split it each time: the S1 layer
+// (64 -> 144 channels at 16x56x56) moves 10.5 GB from the L2s into the CUs for 1.34 GB of HBM traffic (profiles/r01).  Here a
+// block owns 224 consecutive output positions (2 wave columns x 7 MFMA column tiles of 16; 7 because every frame width of
+// the network -- 56, 28, 14, 7 -- is a multiple of 7) and ALL 16*MT rows of one row block, and keeps, per 32-channel block
+// `cb` of the gathered tensor, the whole input patch those positions touch -- their image rows plus one halo row above and below
+// per frame, W + 2 columns -- in LDS as split f16 pairs.  A filter tap is then a constant shift of the LDS row index
+// (dh * (W + 2) + dw): nine K-tiles are served by one gather + one split of ~1.5x the patch instead of nine.
+//
+// LDS image of the patch: one 128-byte row per (image row, column) = [hi plane: 32 channels f16][lo plane], 16-byte chunk L
+// (L = 4 * plane + k / 8) at L ^ (row & 7) -- the layout of igemm_k1s<.., NP = 2>, conflict-free for the fragment reads of 16
+// consecutive rows and for the staging stores.  Two patch buffers (cb, cb + 1).
+//
+// The packed weights of one (cb, tap) K-tile arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction): the pack
+// kernel writes them to global memory in exactly the swizzled LDS image order, so staging them costs the producers no VGPR, no
+// VALU and no ds_write.  Ring of three K-tiles.
+//
+// Waves: 4..7 producers (gather + split + store the NEXT channel block's patch, spread over the current block's nine taps; issue
+// the weight DMA two K-tiles ahead), 0..3 consumers as 2 (rows) x 2 (columns): ceil(MT/2) x 7 accumulator tiles each.  One raw
+// s_barrier per K-tile; the producers wait with counted vmcnt so that the DMA of tile k + 2 stays in flight across it.
+#pragma once
+
+namespace cstp {
+
+constexpr int KP_NPOS = 224;        // output positions per block
+constexpr int KP_NTW = 7;           // 16-column MFMA tiles per consumer wave (two wave columns)
+constexpr int KP_ROWS = 400;        // LDS rows (image positions incl. halo) per patch buffer: the host checks the geometry fits
+constexpr int KP_ROUNDS = (KP_ROWS + 127) / 128;
+
+struct PGeom {
+  int Cs;           // channels of the gathered tensor
+  int ncb;          // its 32-channel blocks
+  int H, W, D, NF;  // frame size, frames per clip, frames in total (Nb * D)
+  int M;            // valid output rows (channels of `out`)
+  int rows_lds;     // LDS rows a tile can touch (<= KP_ROWS)
+};
+
+// packed weights for igemm_k1p: wpk[mblk][kt = cb * 9 + tap][row (16*MT)][physical chunk (8)][8 f16], row m scaled by a power of
+// two (inv_a[m] = its inverse); logical chunk L = 4 * plane + (k % 32) / 8 sits at L ^ (row & 7).  One block per row m.
+// forward: value(m, c, tap) = w[m][c][tap];  data gradient: rows are INPUT channels, k runs over OUTPUT channels and the
+// taps are mirrored: value(m = c_in, c = k_out, tap) = w[k_out][c_in][8 - tap].
+__global__ void __launch_bounds__(256)
+pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, float* __restrict__ inv_a,
+                          unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad) {
+  __shared__ unsigned red[4];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (m == 0 && t < ncells) cells[t] = 0;
+  const int mreal = dgrad ? cin : kout, creal = dgrad ? kout : cin;
+  auto fetch = [&](int c, int tap) __attribute__((always_inline)) -> float {
+    if (m >= mreal || c >= creal) return 0.f;
+    return dgrad ? w[((size_t)c * cin + m) * 9 + (8 - tap)] : w[((size_t)m * cin + c) * 9 + tap];
+  };
+  // one item = 8 consecutive channels of one tap = one 16-byte chunk per plane
+  const int nitems = ncb * 9 * 4;
+  unsigned mx = 0;
+  for (int it = t; it < nitems; it += 256) {
+    const int c8 = it & 3, kt = it >> 2, cb = kt / 9, tap = kt - cb * 9;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned a = __builtin_bit_cast(unsigned, fetch(cb * 32 + c8 * 8 + e, tap)) & 0x7fffffffu;
+      mx = mx > a ? mx : a;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  mx = red[0] > red[1] ? red[0] : red[1];
+  { const unsigned o = red[2] > red[3] ? red[2] : red[3]; mx = mx > o ? mx : o; }
+  float sc, inv;
+  f16_scale(mx, sc, inv);
+  if (t == 0) inv_a[m] = inv;
+  const int mblk = m / rows_per_blk, rloc = m - mblk * rows_per_blk;
+  for (int it = t; it < nitems; it += 256) {
+    const int c8 = it & 3, kt = it >> 2, cb = kt / 9, tap = kt - cb * 9;
+    uint4 ph, pl;
+    unsigned hh, ll;
+    const int c0 = cb * 32 + c8 * 8;
+    split2h(fetch(c0, tap), fetch(c0 + 1, tap), sc, hh, ll); ph.x = hh; pl.x = ll;
+    split2h(fetch(c0 + 2, tap), fetch(c0 + 3, tap), sc, hh, ll); ph.y = hh; pl.y = ll;
+    split2h(fetch(c0 + 4, tap), fetch(c0 + 5, tap), sc, hh, ll); ph.z = hh; pl.z = ll;
+    split2h(fetch(c0 + 6, tap), fetch(c0 + 7, tap), sc, hh, ll); ph.w = hh; pl.w = ll;
+    uint4* row = wpk + (((size_t)mblk * (ncb * 9) + kt) * rows_per_blk + rloc) * 8;
+    row[c8 ^ (rloc & 7)] = ph;
+    row[(4 + c8) ^ (rloc & 7)] = pl;
+  }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(512, 2)
+igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict__ src, float* __restrict__ out,
+          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk) {
+  constexpr int BM = 16 * MT;
+  constexpr int MTW = (MT + 1) / 2;                  // row tiles of the first row-wave (the second takes MT - MTW)
+  constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
+  constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
+  constexpr int P_U4 = KP_ROWS * 8;
+  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + BM / 4];
+  uint4* const ring = smem;
+  uint4* const patch = smem + 3 * A_U4;
+  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // XCD-aware order: the row blocks of one position tile, then the next tile, on consecutive slots of ONE XCD (they share the
+  // patch and the halo rows in that XCD's L2)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int chunk = (ntiles + 7) >> 3;
+  const int t_in = slot / nmblk, mblk = slot - t_in * nmblk;
+  const int tile = xcd * chunk + t_in;
+  if (t_in >= chunk || tile >= ntiles) return;
+
+  const int H = g.H, W = g.W, HW = H * W, PITCH = W + 2;
+  const int P = g.NF * HW;                           // positions in total
+  const int pos0 = tile * KP_NPOS;
+  const int pos_last = (pos0 + KP_NPOS - 1 < P ? pos0 + KP_NPOS - 1 : P - 1);
+  const int v_lo = pos0 / W, v_last = pos_last / W;  // global image rows (frame * H + h) of the tile
+  const int f_lo = v_lo / H;
+  const int nkt = g.ncb * 9;
+  const size_t chs = (size_t)g.D * HW;               // channel stride of src / row stride of out (elements)
+
+  if (wave >= 4) {
+    // ================================================ producers ================================================
+    const int pw = wave - 4;                          // 0..3
+    const int half = pw >> 1;                         // which 16 channels of the 32-channel block this wave gathers
+    const int tp = t - 256, r128 = tp & 127;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)(g.NF / g.D) * g.Cs * chs * 4));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
+    float sb, inv_unused;
+    f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sb, inv_unused);
+
+    // my LDS rows l = r128 + 128 r: byte offset of channel 0 at that (frame, image row, column), or OOB (halo / padding)
+    unsigned voff[KP_ROUNDS];
+    int lrow[KP_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < KP_ROUNDS; ++r) {
+      const int l = r128 + 128 * r;
+      lrow[r] = l;
+      const int line = l / PITCH, col = l - line * PITCH - 1;
+      // line -> (frame, h): frame k of the tile owns (its image rows inside the tile) + 2 lines, halo above and below
+      int rem = line, f = f_lo, v0 = v_lo, h = -1;
+      bool ok = false;
+#pragma unroll 1
+      for (int i = 0; i < 8; ++i) {
+        int fend = (f + 1) * H - 1;
+        fend = fend < v_last ? fend : v_last;
+        const int cnt = fend - v0 + 3;
+        if (rem < cnt) { h = v0 - 1 + rem - f * H; ok = true; break; }
+        rem -= cnt;
+        ++f;
+        v0 = f * H;
+        if (v0 > v_last) break;
+      }
+      ok = ok && h >= 0 && h < H && col >= 0 && col < W && f < g.NF && l < g.rows_lds;
+      const int nb = f / g.D, d = f - nb * g.D;
+      voff[r] = ok ? (unsigned)(((size_t)nb * g.Cs * chs + (size_t)d * HW + h * W + col) * 4) : OOB;
+    }
+    const unsigned ch4 = (unsigned)(chs * 4);
+
+    float rb[2][16];
+    // channels past the tensor's last one (ragged last block) re-read the last channel: their packed weights are zero
+    auto b_load = [&](int cb, int r, float (&v)[16]) __attribute__((always_inline)) {
+      if (128 * r >= g.rows_lds) return;              // uniform: this round's rows lie beyond every tile's patch
+      const int c0 = cb * 32 + half * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int c = c0 + j < g.Cs ? c0 + j : g.Cs - 1;
+        buf_load_x1(v[j], voff[r], rs_src, (unsigned)c * ch4);
+      }
+    };
+    auto b_store = [&](int buf, int r, const float (&v)[16]) __attribute__((always_inline)) {
+      if (128 * r >= g.rows_lds) return;
+      if (lrow[r] >= KP_ROWS) return;
+      uint4 ph[2], pl[2];
+      unsigned hh, ll;
+#define CSTP_SPLITH(J, DST, F) split2h(v[J], v[(J) + 1], sb, hh, ll); ph[DST].F = hh; pl[DST].F = ll;
+      CSTP_SPLITH(0, 0, x) CSTP_SPLITH(2, 0, y) CSTP_SPLITH(4, 0, z) CSTP_SPLITH(6, 0, w)
+      CSTP_SPLITH(8, 1, x) CSTP_SPLITH(10, 1, y) CSTP_SPLITH(12, 1, z) CSTP_SPLITH(14, 1, w)
+#undef CSTP_SPLITH
+      uint4* row = patch + buf * P_U4 + lrow[r] * 8;
+      const int x7 = lrow[r] & 7;
+      row[(2 * half) ^ x7] = ph[0];
+      row[(2 * half + 1) ^ x7] = ph[1];
+      row[(4 + 2 * half) ^ x7] = pl[0];
+      row[(5 + 2 * half) ^ x7] = pl[1];
+    };
+    // weight K-tile kt -> ring slot kt % 3: pieces pw, pw + 4, ... of 1 KiB (lane-linear destination = the packed image order)
+    auto a_dma = [&](int kt) __attribute__((always_inline)) {
+      if (kt >= nkt) return;
+      const unsigned so = (unsigned)((((size_t)mblk * nkt + kt) * A_U4) * 16);
+      uint4* dst = ring + (kt % 3) * A_U4;
+#pragma unroll
+      for (int pc = 0; pc < (A_DMA + 3) / 4; ++pc) {
+        const int piece = pw + 4 * pc;
+        if (piece < A_DMA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
+                                                   (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
+      }
+    };
+
+    // ---- prologue: patch of channel block 0, weight K-tiles 0 and 1
+    a_dma(0);
+    a_dma(1);
+    {
+      float pro[KP_ROUNDS][16];                      // all rounds in flight at once
+#pragma unroll
+      for (int r = 0; r < KP_ROUNDS; ++r) b_load(0, r, pro[r]);
+#pragma unroll
+      for (int r = 0; r < KP_ROUNDS; ++r) b_store(0, r, pro[r]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int cb = 0; cb < g.ncb; ++cb) {
+      const bool more = cb + 1 < g.ncb;               // uniform: a next channel block to stage
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kt = cb * 9 + tap;
+        // K-tile kt + 1 (issued one iteration ago) and every gather issued so far have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) {
+          // rounds of the next patch: loads at taps 0..ROUNDS-1, stores two taps later
+          if (tap >= 2 && tap - 2 < KP_ROUNDS) b_store((cb + 1) & 1, tap - 2, rb[(tap - 2) & 1]);
+          if (tap < KP_ROUNDS) b_load(cb + 1, tap, rb[tap & 1]);
+        }
+        a_dma(kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
+
+  // =================================================== consumers ===================================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int mt0 = wm * MTW;                           // my first row tile; I own MTW (wm = 0) or MT - MTW (wm = 1) of them
+  const int nmt = wm == 0 ? MTW : MT - MTW;           // uniform
+  f32x4 acc[MTW][KP_NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KP_NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  if (t < BM) inva_s[t] = inv_a[mblk * BM + t];
+
+  // LDS row of my column in each of my 7 column tiles, at tap (0, 0); a tap adds dh * PITCH + dw
+  int base[KP_NTW];
+#pragma unroll
+  for (int j = 0; j < KP_NTW; ++j) {
+    int pos = pos0 + (wn * KP_NTW + j) * 16 + fr;
+    pos = pos < P ? pos : P - 1;                      // ragged last tile: compute something valid, never stored
+    const int v = pos / W, w = pos - v * W;
+    base[j] = ((v - v_lo) + 2 * (v / H - f_lo)) * PITCH + w;      // line(v) - 1: tap dh adds dh lines
+  }
+  // my A fragment chunks (rows fr + 16 i: (row & 7) == (fr & 7))
+  const int qa0 = fk ^ (fr & 7), qa1 = (4 + fk) ^ (fr & 7);
+
+  __builtin_amdgcn_s_barrier();                        // prologue data staged
+
+  // one K-tile per iteration, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
+  // 9 x 7 x 2 fragment addresses out of the channel-block loop (126 VGPRs) and spills the accumulators
+  int tap = 0, cb = 0, slot3 = 0, dh_pitch = 0, dw = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    const uint4* Bp = patch + (cb & 1) * P_U4;
+    const uint4* Ab = ring + slot3 * A_U4 + (mt0 * 16 + fr) * 8;
+    const int ts = dh_pitch + dw;
+    f16x8 bh[KP_NTW], bl[KP_NTW];
+#pragma unroll
+    for (int j = 0; j < KP_NTW; ++j) {
+      const int row = base[j] + ts;
+      const int q = fk ^ (row & 7);
+      bh[j] = __builtin_bit_cast(f16x8, Bp[row * 8 + q]);
+      bl[j] = __builtin_bit_cast(f16x8, Bp[row * 8 + (q ^ 4)]);
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (i < nmt) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, Ab[i * 128 + qa0]);
+        const f16x8 al = __builtin_bit_cast(f16x8, Ab[i * 128 + qa1]);
+#pragma unroll
+        for (int j = 0; j < KP_NTW; ++j) {          // small terms first
+          f32x4 a = acc[i][j];
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], a, 0, 0, 0);
+          acc[i][j] = a;
+        }
+      }
+    }
+    // next K-tile: tap runs fastest
+    slot3 = slot3 == 2 ? 0 : slot3 + 1;
+    if (++dw == 3) { dw = 0; dh_pitch += PITCH; }
+    if (++tap == 9) { tap = 0; dh_pitch = 0; ++cb; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Column tiles are stored in pairs: lane groups q and
+  // q ^ 1 swap one register so that 32 consecutive lanes hold 32 consecutive positions of ONE row (whole 128-byte lines); the
+  // seventh tile goes out in 64-byte segments.
+  float invb, sc_unused;
+  f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
+  const int q = lane >> 4;
+  const bool odd = (q & 1) != 0;
+  auto out_base = [&](int pos, bool& ok) __attribute__((always_inline)) -> size_t {
+    ok = pos < P;
+    const int pp = ok ? pos : 0;
+    const int f = pp / HW, sp = pp - f * HW;
+    const int nb = f / g.D, d = f - nb * g.D;
+    return ((size_t)nb * g.M * g.D + d) * HW + sp;
+  };
+#pragma unroll
+  for (int pr = 0; pr < KP_NTW / 2; ++pr) {
+    bool nok;
+    const size_t obase = out_base(pos0 + (wn * KP_NTW + 2 * pr) * 16 + (lane & 31), nok);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (i < nmt) {
+        const int mrow = (mt0 + i) * 16 + (q & ~1) * 4;
+        const f32x4 ia0 = *reinterpret_cast<const f32x4*>(&inva_s[mrow]) * invb;
+        const f32x4 ia1 = *reinterpret_cast<const f32x4*>(&inva_s[mrow + 4]) * invb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = acc[i][2 * pr][r], v1 = acc[i][2 * pr + 1][r];
+          const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
+          const int m_even = mblk * BM + mrow + r, m_odd = m_even + 4;
+          const float ve = (odd ? recv : v0) * ia0[r];
+          const float vo = (odd ? v1 : recv) * ia1[r];
+          if (nok && m_even < g.M) CSTP_STORE(out + obase + (size_t)m_even * chs, ve);
+          if (nok && m_odd < g.M) CSTP_STORE(out + obase + (size_t)m_odd * chs, vo);
+        }
+      }
+    }
+  }
+  {
+    bool nok;
+    const size_t obase = out_base(pos0 + (wn * KP_NTW + KP_NTW - 1) * 16 + fr, nok);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (i < nmt) {
+        const int mrow = (mt0 + i) * 16 + q * 4;
+        const f32x4 ia = *reinterpret_cast<const f32x4*>(&inva_s[mrow]) * invb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mblk * BM + mrow + r;
+          if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][KP_NTW - 1][r] * ia[r]);
+        }
+      }
+    }
+  }
+}
+
+// LDS rows the 224-position tiles of NF frames of H x W touch at most: image rows spanned + 2 halo lines per frame spanned.
+// The tile phase repeats once a tile starts on a frame boundary again, so the scan is short (7 or 14 tiles for this network).
+static inline int patch_rows_needed(int NF, int H, int W) {
+  const long HW = (long)H * W, P = (long)NF * HW;
+  int worst = 0, it = 0;
+  for (long pos0 = 0; pos0 < P; pos0 += KP_NPOS) {
+    if (pos0 > 0 && pos0 % HW == 0) break;
+    if (++it > 4096) return 1 << 30;                  // no short period: not a geometry this kernel is meant for
+    const long last = pos0 + KP_NPOS - 1 < P ? pos0 + KP_NPOS - 1 : P - 1;
+    const long v_lo = pos0 / W, v_last = last / W;
+    const int lines = (int)(v_last - v_lo + 1 + 2 * (v_last / H - v_lo / H + 1));
+    if (lines > worst) worst = lines;
+  }
+  return worst * (W + 2);
+}
+
+}  // namespace cstp

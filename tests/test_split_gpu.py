@@ -211,3 +211,66 @@ def test_absmax_of_unaligned_ragged_and_zero_tensors():
         assert float(z.abs().max()) == 0.0
     finally:
         ops.set_split_terms(0)
+
+
+# ---- the LDS-resident-patch kernel igemm_k1p (csrc/igemm_patch.h): stride-1 1x3x3 layers, forward and data gradient ----------
+PATCH_GEOMS = {
+    "S1": ((2, 64, 4, 14, 14), 144),        # 14x14 frames: tiles of 224 positions straddle frames
+    "S1big": ((1, 64, 2, 56, 56), 144),     # the real S1 frame: tiles = 4 image rows
+    "S3": ((2, 128, 2, 28, 28), 288),       # two row blocks of 144
+    "S7": ((1, 512, 2, 7, 7), 1152),        # 16 channel blocks, one ragged tile of 98 positions spanning two frames
+    "ragged": ((3, 40, 3, 9, 11), 136),     # odd frame size, last channel block 8 of 32, rows padded 136 -> 144
+    "thin": ((2, 16, 1, 5, 6), 24),         # half a channel block, 60 positions
+}
+
+
+@pytest.mark.parametrize("mt_f,mt_d", [(9, 4), (4, 8), (8, 9)])
+@pytest.mark.parametrize("name", list(PATCH_GEOMS))
+def test_patch_kernel_forward_and_data_gradient(name, mt_f, mt_d):
+    from cstp_amd import ops
+    xs, k = PATCH_GEOMS[name]
+    GEOMS["_patch"] = (xs, k, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.set_split_terms(2)
+    try:
+        _run("_patch", {0: (2, mt_f, 0, 0), 1: (2, mt_d, 0, 0), 2: (0, 2, 8, 0)})
+        import ctypes
+        from cstp_amd import _lib
+        out = (ctypes.c_int32 * 4)()
+        desc = ops._desc(xs, (k, xs[1], 1, 3, 3), (1, 1, 1), (0, 1, 1))
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
+        assert list(out)[:3] == [16 * mt_f, 224, 2]          # the pinned patch tile is what runs
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_patch"]
+
+
+def test_patch_kernel_scale_invariance_and_zero_operands():
+    from cstp_amd import ops
+    xs, k = PATCH_GEOMS["S1"]
+    GEOMS["_patch"] = (xs, k, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.set_split_terms(2)
+    try:
+        for sx, sw, sdy in ((1e-20, 1.0, 1e10), (3e18, 1e-12, 1e-10)):
+            _run("_patch", {0: (2, 9, 0, 0), 1: (2, 4, 0, 0), 2: (0, 2, 8, 0)}, scale_x=sx, scale_w=sw, scale_dy=sdy)
+        x = torch.randn(xs, device="cuda")
+        w = torch.randn(k, xs[1], 1, 3, 3, device="cuda")
+        assert float(ops.conv3d(torch.zeros_like(x), w, None, 1, (0, 1, 1)).abs().max()) == 0.0
+        assert float(ops.conv3d(x, torch.zeros_like(w), None, 1, (0, 1, 1)).abs().max()) == 0.0
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_patch"]
+
+
+def test_patch_tile_is_refused_where_the_kernel_does_not_apply():
+    """A patch tile pinned on a strided / temporal / bf16-triple call falls back to another kernel at call time."""
+    from cstp_amd import ops
+    for name in ("S2s", "T1"):
+        _run(name, {0: (2, 9, 0, 0), 1: (2, 4, 0, 0), 2: (0, 2, 8, 0)})
+    xs, k = PATCH_GEOMS["S1"]
+    GEOMS["_patch"] = (xs, k, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.set_split_terms(3)
+    try:
+        _run("_patch", {0: (2, 9, 0, 0), 1: (2, 4, 0, 0), 2: (0, 2, 8, 0)})
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_patch"]
