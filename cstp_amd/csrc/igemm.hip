@@ -1044,7 +1044,15 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
-  dim3 grid((unsigned)(8 * cdiv(ntiles, 8) * nmblk), 1, 1);
+  // persistent blocks, one per CU (the LDS image fills it): 256 of them, or fewer when there is less work
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n / 8 * 8 : 8;
+  }();
+  const int per_xcd = cdiv(ntiles, 8) * nmblk;        // items of the busiest XCD
+  const int slots = per_xcd < n_cu / 8 ? per_xcd : n_cu / 8;
+  dim3 grid((unsigned)(8 * (slots > 0 ? slots : 1)), 1, 1);
 #define CSTP_K1P(MT_) \
   hipLaunchKernelGGL((igemm_k1p<MT_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk)
   if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);

@@ -17,17 +17,24 @@
 // kernel writes them to global memory in exactly the swizzled LDS image order, so staging them costs the producers no VGPR, no
 // VALU and no ds_write.  Ring of three K-tiles.
 //
-// Waves: 4..7 producers (gather + split + store the NEXT channel block's patch, spread over the current block's nine taps; issue
-// the weight DMA two K-tiles ahead), 0..3 consumers as 2 (rows) x 2 (columns): ceil(MT/2) x 7 accumulator tiles each.  One raw
-// s_barrier per K-tile; the producers wait with counted vmcnt so that the DMA of tile k + 2 stays in flight across it.
+// Waves: 6, 7 stage the NEXT channel block's patch (gather + split + store, spread over the current block's nine taps); 4, 5 issue
+// the weight DMA two K-tiles ahead (no other memory instruction, so their wait is counted); 0..3 consumers as 2 (rows) x 2 (columns): ceil(MT/2) x 7 accumulator tiles each.  One raw
+// s_barrier per K-tile.  Blocks are PERSISTENT (one per CU) and the K-tile sequence runs on across a block's work items, so
+// only the first item of a block has an exposed prologue; the consumers fetch the next K-tile's activation fragments (which
+// are in LDS long before) behind the current tile's last products, so only the weight fragments wait for the barrier.
 #pragma once
+
+#include <type_traits>
+
+#ifndef KP_DIAG
+#define KP_DIAG 0     // timing-only diagnostic builds (wrong results): bit 0 = no patch staging after the prologue, bit 1 = no weight
+#endif                // DMA after the prologue, bit 2 = no products, bit 3 = no output stores
 
 namespace cstp {
 
 constexpr int KP_NPOS = 224;        // output positions per block
 constexpr int KP_NTW = 7;           // 16-column MFMA tiles per consumer wave (two wave columns)
 constexpr int KP_ROWS = 400;        // LDS rows (image positions incl. halo) per patch buffer: the host checks the geometry fits
-constexpr int KP_ROUNDS = (KP_ROWS + 127) / 128;
 
 struct PGeom {
   int Cs;           // channels of the gathered tensor
@@ -97,141 +104,193 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
   constexpr int P_U4 = KP_ROWS * 8;
-  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + BM / 4];
+  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4)];
   uint4* const ring = smem;
   uint4* const patch = smem + 3 * A_U4;
-  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);
+  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);      // [2][BM], by item parity
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
-  // XCD-aware order: the row blocks of one position tile, then the next tile, on consecutive slots of ONE XCD (they share the
-  // patch and the halo rows in that XCD's L2)
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
+  // PERSISTENT blocks (one per CU: the LDS image fills it).  Work item = (position tile, row block).  XCD-aware order: XCD x
+  // owns a contiguous chunk of position tiles; its blocks (slots) walk that chunk's items round-robin, so at any moment the
+  // blocks of one XCD work on neighbouring tiles and on the row blocks of the same tile (shared patch and halo rows in L2).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk = (ntiles + 7) >> 3;
-  const int t_in = slot / nmblk, mblk = slot - t_in * nmblk;
-  const int tile = xcd * chunk + t_in;
-  if (t_in >= chunk || tile >= ntiles) return;
+  int tiles_x = ntiles - xcd * chunk;
+  tiles_x = tiles_x < 0 ? 0 : (tiles_x < chunk ? tiles_x : chunk);
+  const int cnt_x = tiles_x * nmblk;                 // items of this XCD
+  const int nitems = slot < cnt_x ? (cnt_x - slot + nslots - 1) / nslots : 0;
+  if (nitems == 0) return;
+  auto item_of = [&](int it, int& tile, int& mblk) __attribute__((always_inline)) {
+    const int idx = slot + it * nslots;
+    const int t_in = idx / nmblk;
+    mblk = idx - t_in * nmblk;
+    tile = xcd * chunk + t_in;
+  };
 
   const int H = g.H, W = g.W, HW = H * W, PITCH = W + 2;
   const int P = g.NF * HW;                           // positions in total
-  const int pos0 = tile * KP_NPOS;
-  const int pos_last = (pos0 + KP_NPOS - 1 < P ? pos0 + KP_NPOS - 1 : P - 1);
-  const int v_lo = pos0 / W, v_last = pos_last / W;  // global image rows (frame * H + h) of the tile
-  const int f_lo = v_lo / H;
   const int nkt = g.ncb * 9;
   const size_t chs = (size_t)g.D * HW;               // channel stride of src / row stride of out (elements)
 
-  if (wave >= 4) {
-    // ================================================ producers ================================================
-    const int pw = wave - 4;                          // 0..3
-    const int half = pw >> 1;                         // which 16 channels of the 32-channel block this wave gathers
-    const int tp = t - 256, r128 = tp & 127;
+  if (wave == 4 || wave == 5) {
+    // ============================================ weight DMA waves (4, 5) ============================================
+    // The K-tile sequence is FLAT across the block's items (nkt is a multiple of 3, so the ring slot sequence simply runs on):
+    // while the consumers finish item i these waves already request item i + 1's first weight K-tiles.  Each wave moves half
+    // of a K-tile's 1 KiB pieces; these waves issue no other vector-memory instruction, so the wait below can be COUNTED: it
+    // leaves the batch just issued (K-tile k + 2) in flight across the barrier and retires K-tile k + 1.
+    constexpr int HALF_DMA = A_DMA / 2;
+    static_assert(A_DMA % 2 == 0, "two DMA waves share a K-tile's pieces evenly");
+    const int dw_ = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
+    int d_it = 0, d_kt = 0, d_mblk, tl_unused;
+    item_of(0, tl_unused, d_mblk);
+    auto dma_next = [&]() __attribute__((always_inline)) {
+      // past the last item the requests re-read its last K-tile into a ring slot nobody reads any more: the instruction
+      // count per iteration stays constant, which is what the counted wait relies on
+      const unsigned so = (unsigned)((((size_t)d_mblk * nkt + d_kt) * A_U4) * 16);
+      uint4* dst = ring + (d_kt % 3) * A_U4;
+#pragma unroll
+      for (int pc = 0; pc < HALF_DMA; ++pc) {
+        const int piece = dw_ * HALF_DMA + pc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
+                                                 (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
+      }
+      if (d_it + 1 < nitems || d_kt + 1 < nkt) {
+        if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
+      }
+    };
+    dma_next();
+    dma_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int total = nitems * nkt;
+#pragma unroll 1
+    for (int k = 0; k < total; ++k) {
+      if (!(KP_DIAG & 2)) dma_next();                 // K-tile k + 2 -> the slot K-tile k - 1 was read from
+      if constexpr (HALF_DMA == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if constexpr (HALF_DMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  if (wave >= 6) {
+    // ============================================ patch staging waves (6, 7) ============================================
+    // Wave 6 gathers channels 0..15 of each 32-channel block, wave 7 channels 16..31; lane l owns LDS rows l + 64 r.  They share
+    // their SIMDs with the second row-wave's consumers (waves 2, 3), which own one row tile fewer when MT is odd.  Seven rounds
+    // of (16 dword gathers -> split -> four 16-byte LDS stores) stage the NEXT channel block's patch while the current one is
+    // multiplied: round r loads at tap r and stores at tap r + 2.  No load is conditional -- a round with nothing to stage
+    // gathers through out-of-range offsets (zeros, no memory traffic) -- so the compiler's s_waitcnt accounting keeps two
+    // rounds in flight with counted waits (igemm_split.h explains what a conditional load costs).
+    constexpr int NR = (KP_ROWS + 63) / 64;            // 7
+    static_assert(NR <= 7, "rounds must fit the nine taps of a channel block");
+    const int half = wave - 6;
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)(g.NF / g.D) * g.Cs * chs * 4));
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
     float sb, inv_unused;
     f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sb, inv_unused);
 
-    // my LDS rows l = r128 + 128 r: byte offset of channel 0 at that (frame, image row, column), or OOB (halo / padding)
-    unsigned voff[KP_ROUNDS];
-    int lrow[KP_ROUNDS];
+    // byte offset of channel 0 at the (frame, image row, column) of my LDS rows in a tile's patch, or OOB (halo / padding)
+    auto patch_offsets = [&](int tile, unsigned (&voff)[NR]) __attribute__((always_inline)) {
+      const int pos0 = tile * KP_NPOS;
+      const int pos_last = (pos0 + KP_NPOS - 1 < P ? pos0 + KP_NPOS - 1 : P - 1);
+      const int v_lo = pos0 / W, v_last = pos_last / W;
+      const int f_lo = v_lo / H;
 #pragma unroll
-    for (int r = 0; r < KP_ROUNDS; ++r) {
-      const int l = r128 + 128 * r;
-      lrow[r] = l;
-      const int line = l / PITCH, col = l - line * PITCH - 1;
-      // line -> (frame, h): frame k of the tile owns (its image rows inside the tile) + 2 lines, halo above and below
-      int rem = line, f = f_lo, v0 = v_lo, h = -1;
-      bool ok = false;
+      for (int r = 0; r < NR; ++r) {
+        const int l = lane + 64 * r;
+        const int line = l / PITCH, col = l - line * PITCH - 1;
+        // line -> (frame, h): frame k of the tile owns (its image rows inside the tile) + 2 lines, halo above and below
+        int rem = line, f = f_lo, v0 = v_lo, h = -1;
+        bool ok = false;
 #pragma unroll 1
-      for (int i = 0; i < 8; ++i) {
-        int fend = (f + 1) * H - 1;
-        fend = fend < v_last ? fend : v_last;
-        const int cnt = fend - v0 + 3;
-        if (rem < cnt) { h = v0 - 1 + rem - f * H; ok = true; break; }
-        rem -= cnt;
-        ++f;
-        v0 = f * H;
-        if (v0 > v_last) break;
+        for (int i = 0; i < 8; ++i) {
+          int fend = (f + 1) * H - 1;
+          fend = fend < v_last ? fend : v_last;
+          const int cnt = fend - v0 + 3;
+          if (rem < cnt) { h = v0 - 1 + rem - f * H; ok = true; break; }
+          rem -= cnt;
+          ++f;
+          v0 = f * H;
+          if (v0 > v_last) break;
+        }
+        ok = ok && h >= 0 && h < H && col >= 0 && col < W && f < g.NF && l < g.rows_lds;
+        const int nb = f / g.D, d = f - nb * g.D;
+        voff[r] = ok ? (unsigned)(((size_t)nb * g.Cs * chs + (size_t)d * HW + h * W + col) * 4) : OOB;
       }
-      ok = ok && h >= 0 && h < H && col >= 0 && col < W && f < g.NF && l < g.rows_lds;
-      const int nb = f / g.D, d = f - nb * g.D;
-      voff[r] = ok ? (unsigned)(((size_t)nb * g.Cs * chs + (size_t)d * HW + h * W + col) * 4) : OOB;
-    }
+    };
     const unsigned ch4 = (unsigned)(chs * 4);
-
-    float rb[2][16];
     // channels past the tensor's last one (ragged last block) re-read the last channel: their packed weights are zero
-    auto b_load = [&](int cb, int r, float (&v)[16]) __attribute__((always_inline)) {
-      if (128 * r >= g.rows_lds) return;              // uniform: this round's rows lie beyond every tile's patch
+    auto b_load = [&](unsigned vo, int cb, float (&v)[16]) __attribute__((always_inline)) {
       const int c0 = cb * 32 + half * 16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = c0 + j < g.Cs ? c0 + j : g.Cs - 1;
-        buf_load_x1(v[j], voff[r], rs_src, (unsigned)c * ch4);
+        buf_load_x1(v[j], vo, rs_src, (unsigned)c * ch4);
       }
     };
     auto b_store = [&](int buf, int r, const float (&v)[16]) __attribute__((always_inline)) {
-      if (128 * r >= g.rows_lds) return;
-      if (lrow[r] >= KP_ROWS) return;
+      const int l = lane + 64 * r;
       uint4 ph[2], pl[2];
       unsigned hh, ll;
 #define CSTP_SPLITH(J, DST, F) split2h(v[J], v[(J) + 1], sb, hh, ll); ph[DST].F = hh; pl[DST].F = ll;
       CSTP_SPLITH(0, 0, x) CSTP_SPLITH(2, 0, y) CSTP_SPLITH(4, 0, z) CSTP_SPLITH(6, 0, w)
       CSTP_SPLITH(8, 1, x) CSTP_SPLITH(10, 1, y) CSTP_SPLITH(12, 1, z) CSTP_SPLITH(14, 1, w)
 #undef CSTP_SPLITH
-      uint4* row = patch + buf * P_U4 + lrow[r] * 8;
-      const int x7 = lrow[r] & 7;
-      row[(2 * half) ^ x7] = ph[0];
-      row[(2 * half + 1) ^ x7] = ph[1];
-      row[(4 + 2 * half) ^ x7] = pl[0];
-      row[(5 + 2 * half) ^ x7] = pl[1];
-    };
-    // weight K-tile kt -> ring slot kt % 3: pieces pw, pw + 4, ... of 1 KiB (lane-linear destination = the packed image order)
-    auto a_dma = [&](int kt) __attribute__((always_inline)) {
-      if (kt >= nkt) return;
-      const unsigned so = (unsigned)((((size_t)mblk * nkt + kt) * A_U4) * 16);
-      uint4* dst = ring + (kt % 3) * A_U4;
-#pragma unroll
-      for (int pc = 0; pc < (A_DMA + 3) / 4; ++pc) {
-        const int piece = pw + 4 * pc;
-        if (piece < A_DMA)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
-                                                   (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
+      if (l < KP_ROWS) {
+        uint4* row = patch + buf * P_U4 + l * 8;
+        const int x7 = l & 7;
+        row[(2 * half) ^ x7] = ph[0];
+        row[(2 * half + 1) ^ x7] = ph[1];
+        row[(4 + 2 * half) ^ x7] = pl[0];
+        row[(5 + 2 * half) ^ x7] = pl[1];
       }
     };
 
-    // ---- prologue: patch of channel block 0, weight K-tiles 0 and 1
-    a_dma(0);
-    a_dma(1);
+    unsigned voff_cur[NR], voff_nxt[NR];
+    int tile, mb_unused;
+    item_of(0, tile, mb_unused);
+    patch_offsets(tile, voff_cur);
+    // ---- prologue: the first item's channel block 0, all rounds in flight at once
     {
-      float pro[KP_ROUNDS][16];                      // all rounds in flight at once
+      float pro[NR][16];
 #pragma unroll
-      for (int r = 0; r < KP_ROUNDS; ++r) b_load(0, r, pro[r]);
+      for (int r = 0; r < NR; ++r) b_load(voff_cur[r], 0, pro[r]);
 #pragma unroll
-      for (int r = 0; r < KP_ROUNDS; ++r) b_store(0, r, pro[r]);
+      for (int r = 0; r < NR; ++r) b_store(0, r, pro[r]);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int cb = 0; cb < g.ncb; ++cb) {
-      const bool more = cb + 1 < g.ncb;               // uniform: a next channel block to stage
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int kt = cb * 9 + tap;
-        // K-tile kt + 1 (issued one iteration ago) and every gather issued so far have landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (more) {
-          // rounds of the next patch: loads at taps 0..ROUNDS-1, stores two taps later
-          if (tap >= 2 && tap - 2 < KP_ROUNDS) b_store((cb + 1) & 1, tap - 2, rb[(tap - 2) & 1]);
-          if (tap < KP_ROUNDS) b_load(cb + 1, tap, rb[tap & 1]);
+    float rb[2][16];
+    int pb = 0;                                       // patch buffer of the channel block being consumed
+    for (int it = 0; it < nitems; ++it) {
+      const bool next_item = it + 1 < nitems;
+      for (int cb = 0; cb < g.ncb; ++cb) {
+        const bool last_cb = cb + 1 == g.ncb;
+        const bool stage = (!last_cb || next_item) && !(KP_DIAG & 1);   // a next channel block (of this or the next item)
+        if (last_cb && next_item) {
+          item_of(it + 1, tile, mb_unused);
+          patch_offsets(tile, voff_nxt);
         }
-        a_dma(kt + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        const int ncb_ = last_cb ? 0 : cb + 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap >= 2 && tap - 2 < NR) b_store(pb ^ 1, tap - 2, rb[tap & 1]);
+          if (tap < NR) {
+            const unsigned vo = stage ? (last_cb ? voff_nxt[tap] : voff_cur[tap]) : OOB;
+            b_load(vo, ncb_, rb[tap & 1]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        pb ^= 1;
       }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) voff_cur[r] = voff_nxt[r];
     }
     return;
   }
@@ -240,122 +299,167 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
   const int mt0 = wm * MTW;                           // my first row tile; I own MTW (wm = 0) or MT - MTW (wm = 1) of them
-  const int nmt = wm == 0 ? MTW : MT - MTW;           // uniform
-  f32x4 acc[MTW][KP_NTW];
-#pragma unroll
-  for (int i = 0; i < MTW; ++i)
-#pragma unroll
-    for (int j = 0; j < KP_NTW; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-  if (t < BM) inva_s[t] = inv_a[mblk * BM + t];
-
-  // LDS row of my column in each of my 7 column tiles, at tap (0, 0); a tap adds dh * PITCH + dw
-  int base[KP_NTW];
-#pragma unroll
-  for (int j = 0; j < KP_NTW; ++j) {
-    int pos = pos0 + (wn * KP_NTW + j) * 16 + fr;
-    pos = pos < P ? pos : P - 1;                      // ragged last tile: compute something valid, never stored
-    const int v = pos / W, w = pos - v * W;
-    base[j] = ((v - v_lo) + 2 * (v / H - f_lo)) * PITCH + w;      // line(v) - 1: tap dh adds dh lines
-  }
   // my A fragment chunks (rows fr + 16 i: (row & 7) == (fr & 7))
   const int qa0 = fk ^ (fr & 7), qa1 = (4 + fk) ^ (fr & 7);
-
-  __builtin_amdgcn_s_barrier();                        // prologue data staged
-
-  // one K-tile per iteration, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
-  // 9 x 7 x 2 fragment addresses out of the channel-block loop (126 VGPRs) and spills the accumulators
-  int tap = 0, cb = 0, slot3 = 0, dh_pitch = 0, dw = 0;
-#pragma unroll 1
-  for (int kt = 0; kt < nkt; ++kt) {
-    const uint4* Bp = patch + (cb & 1) * P_U4;
-    const uint4* Ab = ring + slot3 * A_U4 + (mt0 * 16 + fr) * 8;
-    const int ts = dh_pitch + dw;
-    f16x8 bh[KP_NTW], bl[KP_NTW];
-#pragma unroll
-    for (int j = 0; j < KP_NTW; ++j) {
-      const int row = base[j] + ts;
-      const int q = fk ^ (row & 7);
-      bh[j] = __builtin_bit_cast(f16x8, Bp[row * 8 + q]);
-      bl[j] = __builtin_bit_cast(f16x8, Bp[row * 8 + (q ^ 4)]);
-    }
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (i < nmt) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, Ab[i * 128 + qa0]);
-        const f16x8 al = __builtin_bit_cast(f16x8, Ab[i * 128 + qa1]);
-#pragma unroll
-        for (int j = 0; j < KP_NTW; ++j) {          // small terms first
-          f32x4 a = acc[i][j];
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], a, 0, 0, 0);
-          acc[i][j] = a;
-        }
-      }
-    }
-    // next K-tile: tap runs fastest
-    slot3 = slot3 == 2 ? 0 : slot3 + 1;
-    if (++dw == 3) { dw = 0; dh_pitch += PITCH; }
-    if (++tap == 9) { tap = 0; dh_pitch = 0; ++cb; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Column tiles are stored in pairs: lane groups q and
-  // q ^ 1 swap one register so that 32 consecutive lanes hold 32 consecutive positions of ONE row (whole 128-byte lines); the
-  // seventh tile goes out in 64-byte segments.
   float invb, sc_unused;
   f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
   const int q = lane >> 4;
   const bool odd = (q & 1) != 0;
-  auto out_base = [&](int pos, bool& ok) __attribute__((always_inline)) -> size_t {
-    ok = pos < P;
-    const int pp = ok ? pos : 0;
-    const int f = pp / HW, sp = pp - f * HW;
-    const int nb = f / g.D, d = f - nb * g.D;
-    return ((size_t)nb * g.M * g.D + d) * HW + sp;
-  };
+
+  __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
+  __builtin_amdgcn_s_setprio(2);                       // the matrix stream outranks the staging waves it shares SIMDs with
+
+  // NI = row tiles of this wave: MTW for the first row-wave, MT - MTW for the second (one fewer when MT is odd) -- two
+  // instantiations of the body instead of a branch around every fifth product
+  auto body = [&](auto ni_tag) __attribute__((always_inline)) {
+  constexpr int NI = decltype(ni_tag)::value;
+  int pb = 0;
+  for (int it = 0; it < nitems; ++it) {
+    int tile, mblk;
+    item_of(it, tile, mblk);
+    const int pos0 = tile * KP_NPOS;
+    const int v_lo = pos0 / W, f_lo = v_lo / H;
+    float* const inva = inva_s + (it & 1) * BM;
+    if (t < BM) inva[t] = inv_a[mblk * BM + t];       // read back in this item's epilogue, >= 9 barriers later
+
+    f32x4 acc[NI][KP_NTW];
 #pragma unroll
-  for (int pr = 0; pr < KP_NTW / 2; ++pr) {
-    bool nok;
-    const size_t obase = out_base(pos0 + (wn * KP_NTW + 2 * pr) * 16 + (lane & 31), nok);
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (i < nmt) {
-        const int mrow = (mt0 + i) * 16 + (q & ~1) * 4;
-        const f32x4 ia0 = *reinterpret_cast<const f32x4*>(&inva_s[mrow]) * invb;
-        const f32x4 ia1 = *reinterpret_cast<const f32x4*>(&inva_s[mrow + 4]) * invb;
+      for (int j = 0; j < KP_NTW; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v0 = acc[i][2 * pr][r], v1 = acc[i][2 * pr + 1][r];
-          const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
-          const int m_even = mblk * BM + mrow + r, m_odd = m_even + 4;
-          const float ve = (odd ? recv : v0) * ia0[r];
-          const float vo = (odd ? v1 : recv) * ia1[r];
-          if (nok && m_even < g.M) CSTP_STORE(out + obase + (size_t)m_even * chs, ve);
-          if (nok && m_odd < g.M) CSTP_STORE(out + obase + (size_t)m_odd * chs, vo);
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // LDS row of my column in each of my 7 column tiles, one line above / one column left of it; a tap adds dh * PITCH + dw
+    int base[KP_NTW];
+#pragma unroll
+    for (int j = 0; j < KP_NTW; ++j) {
+      int pos = pos0 + (wn * KP_NTW + j) * 16 + fr;
+      pos = pos < P ? pos : P - 1;                    // ragged last tile: compute something valid, never stored
+      const int v = pos / W, w = pos - v * W;
+      base[j] = ((v - v_lo) + 2 * (v / H - f_lo)) * PITCH + w;
+    }
+
+    // B fragments (my column tile j at one tap) are double buffered in registers and fetched one column tile ahead -- they sit
+    // in LDS long before they are needed, also the next K-tile's; only the weight fragments wait for the barrier, and of
+    // those only the first row tile's two reads are exposed.  Loop order: column tile outer, row tile inner (independent
+    // accumulators back to back).
+    f16x8 bh[2], bl[2];
+    auto load_b = [&](int buf, int j, const uint4* Bp, int ts) __attribute__((always_inline)) {
+      const int row = base[j] + ts;
+      const int qq = fk ^ (row & 7);
+      bh[buf] = __builtin_bit_cast(f16x8, Bp[row * 8 + qq]);
+      bl[buf] = __builtin_bit_cast(f16x8, Bp[row * 8 + (qq ^ 4)]);
+    };
+    load_b(0, 0, patch + pb * P_U4, 0);               // K-tile 0 of this item: already staged
+    const int arow0 = (mt0 * 16 + fr) * 8;
+
+    // one K-tile per iteration, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
+    // 9 x 7 x 2 fragment addresses out of the loop (126 VGPRs) and spills the accumulators
+    int tap = 0, slot3 = 0, dh_pitch = 0, dw = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+      const uint4* Ab = ring + slot3 * A_U4;
+      const uint4* Bp = patch + pb * P_U4;
+      const int ts = dh_pitch + dw;
+      // the NEXT K-tile's tap shift / patch buffer
+      int ntap = tap + 1, ndw = dw + 1, ndh = dh_pitch, npb = pb;
+      if (ndw == 3) { ndw = 0; ndh += PITCH; }
+      if (ntap == 9) { ntap = 0; ndh = 0; npb ^= 1; }
+      const uint4* Bn = patch + npb * P_U4;
+      const int nts = ndh + ndw;
+
+      f16x8 ah[NI], al[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        ah[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa0]);
+        al[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa1]);
+      }
+#pragma unroll
+      for (int j = 0; j < KP_NTW; ++j) {
+        if (j + 1 < KP_NTW) load_b((j + 1) & 1, j + 1, Bp, ts);
+        else load_b((j + 1) & 1, 0, Bn, nts);         // (past the item's last K-tile: a harmless read, reloaded below)
+        const f16x8 bhj = bh[j & 1], blj = bl[j & 1];
+#if KP_DIAG & 4
+        asm volatile("" :: "v"(bhj), "v"(blj));
+        if (j == 0) { _Pragma("unroll") for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(ah[i]), "v"(al[i])); }
+        continue;
+#endif
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bhj, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], blj, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bhj, acc[i][j], 0, 0, 0);
+      }
+      // (KP_NTW is odd: the next K-tile's first fragments landed in buffer KP_NTW & 1 -- move them to buffer 0)
+      bh[0] = bh[KP_NTW & 1];
+      bl[0] = bl[KP_NTW & 1];
+      slot3 = slot3 == 2 ? 0 : slot3 + 1;
+      tap = ntap; dw = ndw; dh_pitch = ndh; pb = npb;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // (pb has moved on to the buffer that holds the next item's first channel block)
+
+    // ---- epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Column tiles are stored in pairs: lane groups q
+    // and q ^ 1 swap one register so that 32 consecutive lanes hold 32 consecutive positions of ONE row (whole 128-byte
+    // lines); the seventh tile goes out in 64-byte segments.
+    auto out_base = [&](int pos, bool& ok) __attribute__((always_inline)) -> size_t {
+      ok = pos < P;
+      const int pp = ok ? pos : 0;
+      const int f = pp / HW, sp = pp - f * HW;
+      const int nb = f / g.D, d = f - nb * g.D;
+      return ((size_t)nb * g.M * g.D + d) * HW + sp;
+    };
+#pragma unroll
+    for (int pr = 0; pr < KP_NTW / 2; ++pr) {
+      bool nok;
+      const size_t obase = out_base(pos0 + (wn * KP_NTW + 2 * pr) * 16 + (lane & 31), nok);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        {
+          const int mrow = (mt0 + i) * 16 + (q & ~1) * 4;
+          const f32x4 ia0 = *reinterpret_cast<const f32x4*>(&inva[mrow]) * invb;
+          const f32x4 ia1 = *reinterpret_cast<const f32x4*>(&inva[mrow + 4]) * invb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v0 = acc[i][2 * pr][r], v1 = acc[i][2 * pr + 1][r];
+            const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
+            const int m_even = mblk * BM + mrow + r, m_odd = m_even + 4;
+            const float ve = (odd ? recv : v0) * ia0[r];
+            const float vo = (odd ? v1 : recv) * ia1[r];
+            if ((KP_DIAG & 8) && ve != 12345.f) continue;
+            if (nok && m_even < g.M) CSTP_STORE(out + obase + (size_t)m_even * chs, ve);
+            if (nok && m_odd < g.M) CSTP_STORE(out + obase + (size_t)m_odd * chs, vo);
+          }
+        }
+      }
+    }
+    {
+      bool nok;
+      const size_t obase = out_base(pos0 + (wn * KP_NTW + KP_NTW - 1) * 16 + fr, nok);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        {
+          const int mrow = (mt0 + i) * 16 + q * 4;
+          const f32x4 ia = *reinterpret_cast<const f32x4*>(&inva[mrow]) * invb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mblk * BM + mrow + r;
+            if ((KP_DIAG & 8) && acc[i][KP_NTW - 1][r] != 12345.f) continue;
+            if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][KP_NTW - 1][r] * ia[r]);
+          }
         }
       }
     }
   }
-  {
-    bool nok;
-    const size_t obase = out_base(pos0 + (wn * KP_NTW + KP_NTW - 1) * 16 + fr, nok);
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (i < nmt) {
-        const int mrow = (mt0 + i) * 16 + q * 4;
-        const f32x4 ia = *reinterpret_cast<const f32x4*>(&inva_s[mrow]) * invb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = mblk * BM + mrow + r;
-          if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][KP_NTW - 1][r] * ia[r]);
-        }
-      }
-    }
+  };
+  if constexpr (MT - MTW == MTW) {
+    body(std::integral_constant<int, MTW>{});
+  } else {
+    if (wm == 0) body(std::integral_constant<int, MTW>{});
+    else body(std::integral_constant<int, MT - MTW>{});
   }
 }
 
