@@ -44,6 +44,10 @@ SIGNATURES = {
     "cstp_conv3d_forward_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, POINTER(InAffine), _P, _P, c_size_t, _P]),
     "cstp_conv3d_backward_data_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "cstp_conv3d_backward_weight_am": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P]),
+    "cstp_conv3d_backward_weight_acc": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P,
+                                                 c_int32]),
+    "cstp_set_deterministic": (c_int32, [c_int32]),
+    "cstp_get_deterministic": (c_int32, []),
     "cstp_gemm_set_split_terms": (c_int32, [c_int32]),
     "cstp_gemm_get_split_terms": (c_int32, []),
     "cstp_conv3d_query_tile": (c_int32, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),

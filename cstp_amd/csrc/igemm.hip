@@ -80,10 +80,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// split-K output of the weight-gradient kernels: f32 atomics into ONE slab (default), or a plain store into this split's own
+// slab (deterministic mode: cstp_set_deterministic; unpack_wgrad_kernel then sums the slabs in a fixed order)
+__device__ __forceinline__ void wgrad_out(float* p, float v, bool det) {
+  if (det) *p = v; else atomicAdd(p, v);
+}
+
 // dw[m][c][tap] = dwp[m][tap*Cp + c]  (x inv_x x inv_dy: the absmax cells of the 2xf16-split kernel, else null)
 __device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, float& inv);
+// nslabs > 1 (deterministic mode): the split-K partial slabs are summed here in a fixed order instead of by atomics.
+// accumulate: dw += (the caller's gradient accumulation, e.g. straight into the flat gradient arena) instead of dw =.
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int M, int cin, int ntaps,
-                                    int Cp, int Jp, const unsigned* __restrict__ xcell, const unsigned* __restrict__ dycell) {
+                                    int Cp, int Jp, const unsigned* __restrict__ xcell, const unsigned* __restrict__ dycell,
+                                    int nslabs, size_t slab_stride, int accumulate) {
   float i0 = 1.f, i1 = 1.f;
   if (xcell != nullptr) { float sc; f16_scale(*xcell, sc, i0); f16_scale(*dycell, sc, i1); }
   const size_t total = (size_t)M * cin * ntaps;
@@ -92,7 +101,11 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
     const size_t r = i / ntaps;
     const int c = (int)(r % cin);
     const int m = (int)(r / cin);
-    dw[i] = dwp[(size_t)m * Jp + tap * Cp + c] * i0 * i1;
+    const float* p = dwp + (size_t)m * Jp + tap * Cp + c;
+    float v = p[0];
+    for (int sidx = 1; sidx < nslabs; ++sidx) v += p[(size_t)sidx * slab_stride];
+    v = v * i0 * i1;
+    dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
@@ -444,7 +457,7 @@ template <int MT, bool STRADDLE, bool VEC4, int BKN, bool XFORM, bool M16>
 __global__ void __launch_bounds__(256)
 igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot,
          int Jp, int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit,
-         const float2* __restrict__ in_ss, int in_npg, int in_groups, int in_relu) {
+         const float2* __restrict__ in_ss, int in_npg, int in_groups, int in_relu, size_t det_stride) {
   // Block tile (32*MT) x 128 outputs; the reduction runs over positions in tiles of 32, staged
   // global -> registers -> LDS ([row][pos], row stride 33: conflict-free both for the coalesced
   // stores along pos and for the MFMA operand reads along rows) with the NEXT tile's loads in flight
@@ -677,7 +690,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = m0 + mt * 16 + (lane >> 4) * 4 + r;
-            if (m < g.M) atomicAdd(&dwp[(size_t)m * Jp + j], acc16[mt][nt][r]);
+            if (m < g.M) wgrad_out(&dwp[(size_t)split * det_stride + (size_t)m * Jp + j], acc16[mt][nt][r], det_stride != 0);
           }
         }
       }
@@ -691,7 +704,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-        if (m < g.M) atomicAdd(&dwp[(size_t)m * Jp + j], acc[mt][r]);
+        if (m < g.M) wgrad_out(&dwp[(size_t)split * det_stride + (size_t)m * Jp + j], acc[mt][r], det_stride != 0);
       }
     }
   }
@@ -891,6 +904,19 @@ static bool native_only() {
   }();
   return env_f32 || g_split_terms.load(std::memory_order_relaxed) == 1;
 }
+// deterministic mode (cstp_set_deterministic / CSTP_DETERMINISTIC=1): weight gradients through a two-stage split-K reduction
+// (every split writes its own slab, unpack sums them in order) instead of f32 atomics: bit-reproducible, for debugging
+constexpr int DET_MAX_SPLITS = 32;
+static std::atomic<int> g_deterministic{-1};
+static bool deterministic() {
+  int v = g_deterministic.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("CSTP_DETERMINISTIC");
+    v = (e != nullptr && e[0] == '1') ? 1 : 0;
+    g_deterministic.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
 // tail of the workspace: [0, 256) absmax cells of the activation operand(s), then the per-row inverse scales of the packed
 // weights (<= max(k, c) + 160 rows)
 static size_t plan_tail_bytes(const cstp_conv_desc& d) { return 256 + align_up((size_t)((d.k > d.c ? d.k : d.c) + 160) * 4, 256); }
@@ -907,7 +933,7 @@ static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
     if (pf > f) f = pf;
     if (pg > g) g = pg;
   }
-  size_t w = (size_t)d.k * p.w_Jp * sizeof(float);
+  size_t w = align_up((size_t)d.k * p.w_Jp * sizeof(float), 256) * (deterministic() ? DET_MAX_SPLITS : 1);
   size_t m = f > g ? f : g;
   if (w > m) m = w;
   return align_up(m, 256);
@@ -952,14 +978,14 @@ static void launch_k1(Tile tl, dim3 grid, hipStream_t s, const Geom& g, const fl
 template <bool STRADDLE, bool VEC4, int BKN, bool XFORM>
 static void launch_k2(int mt, dim3 grid, hipStream_t s, const Geom& g, const float* dy, const float* x, float* dwp,
                       int Jtot, int Jp, int kt_total, int kt_per, int ntm, int ntj, int nsplit, const float2* in_ss,
-                      int in_npg, int in_groups, int in_relu) {
+                      int in_npg, int in_groups, int in_relu, size_t det_stride) {
 #define CSTP_K2(MT_)                                                                                              \
   hipLaunchKernelGGL((igemm_k2<MT_, STRADDLE, VEC4, BKN, XFORM, false>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp, \
-                     kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu)
+                     kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu, det_stride)
   if (mt == 9) {   // 144-row tile on the 16x16x4 MFMA
     if (!STRADDLE)
       hipLaunchKernelGGL((igemm_k2<9, false, VEC4, BKN, XFORM, true>), grid, dim3(256), 0, s, g, dy, x, dwp, Jtot, Jp,
-                         kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu);
+                         kt_total, kt_per, ntm, ntj, nsplit, in_ss, in_npg, in_groups, in_relu, det_stride);
     return;
   }
   switch (mt) {
@@ -1192,6 +1218,20 @@ extern "C" int cstp_conv3d_backward_weight(void* stream, const cstp_conv_desc* d
 extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x,
                                               const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                               size_t ws_bytes, const uint32_t* x_absmax, const uint32_t* dy_absmax) {
+  return cstp_conv3d_backward_weight_acc(stream, desc, x, in_affine, dy, dw, ws, ws_bytes, x_absmax, dy_absmax, 0);
+}
+
+extern "C" int cstp_set_deterministic(int32_t on) {
+  g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+
+extern "C" int32_t cstp_get_deterministic(void) { return deterministic() ? 1 : 0; }
+
+extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_desc* desc, const float* x,
+                                               const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
+                                               size_t ws_bytes, const uint32_t* x_absmax, const uint32_t* dy_absmax,
+                                               int32_t accumulate) {
   CSTP_REQUIRE(desc && x && dy && dw && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1204,8 +1244,7 @@ extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc
   const size_t slab = (size_t)d.k * p.w_Jp * sizeof(float);
   // the absmax cells of the 2xf16-split kernel sit right behind the slab (256-byte aligned) and are zeroed with it
   const size_t slab_al = align_up(slab, 256);
-  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + slab_al);
-  if (hipMemsetAsync(dwp, 0, slab_al + 256, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+  const bool det = deterministic();
   Geom g;
   g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;         // gather from x
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;      // reduction over dy positions
@@ -1222,18 +1261,25 @@ extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc
   const int ntm = w_split ? cdiv(d.k, 16 * p.w_mt) : cdiv(d.k, p.w_mt == 9 ? 144 : 32 * p.w_mt), ntj = cdiv(p.w_Jtot, 128);
   int splits = cdiv(p.w_blocks, ntm * ntj);
   if (splits > cdiv(kt_total, 256 / bkn)) splits = cdiv(kt_total, 256 / bkn);
+  if (det && splits > DET_MAX_SPLITS) splits = DET_MAX_SPLITS;
   if (splits < 1) splits = 1;
   const int kt_per = cdiv(kt_total, splits);
   splits = cdiv(kt_total, kt_per);
+  // one slab filled by atomics, or (deterministic) one slab per split; the absmax cells sit in the workspace tail
+  // (the absmax cells of the 2xf16-split kernel sit right behind the slab(s), 256-byte aligned, and are zeroed with them)
+  const size_t det_stride = det ? slab_al / sizeof(float) : 0;
+  const size_t slabs_bytes = slab_al * (det ? splits : 1);
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + slabs_bytes);
+  if (hipMemsetAsync(dwp, 0, slabs_bytes + 256, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
   dim3 grid((unsigned)(align_up((size_t)splits * ntm, 8) * ntj), 1, 1);
   const bool v4 = ((p.Do * p.Ho * p.Wo) % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-#define CSTP_K2_ARGS p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, ia.ss, ia.npg, ia.groups, ia.relu
+#define CSTP_K2_ARGS p.w_mt, grid, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, ia.ss, ia.npg, ia.groups, ia.relu, det_stride
   const bool w_f16 = w_split && split_planes() == 2;
   const unsigned* xcell = x_absmax != nullptr ? x_absmax : cells;
   const unsigned* dycell = dy_absmax != nullptr ? dy_absmax : cells + 1;
   if (w_split) {
 #define CSTP_K2S(MT_, NP_) \
-  hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell)
+  hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell, det_stride)
     if (w_f16) {
       const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
       if (x_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(nx)), dim3(256), 0, s, x, nx, cells);
@@ -1257,7 +1303,7 @@ extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc
   CSTP_LAUNCH_CHECK();
   const size_t tot = (size_t)d.k * d.c * p.ntaps;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp,
-                     w_f16 ? xcell : nullptr, w_f16 ? dycell : nullptr);
+                     w_f16 ? xcell : nullptr, w_f16 ? dycell : nullptr, det ? splits : 1, det_stride, accumulate ? 1 : 0);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

@@ -636,7 +636,7 @@ template <int MT, int NP>
 __global__ void __launch_bounds__(512, NP == 2 ? 4 : 1)      // f16 pair: the LDS images fit twice into a CU (4 waves per SIMD: <= 128 VGPRs)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
           int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit, const unsigned* __restrict__ xcell,
-          const unsigned* __restrict__ dycell) {
+          const unsigned* __restrict__ dycell, size_t det_stride) {
   static_assert(MT == 4 || MT == 8 || MT == 9, "row tiles: 64 or 128 main rows (+16)");
   static_assert(NP == 2 || NP == 3, "planes per operand");
   constexpr int BM = 16 * MT, BJ = 128;
@@ -915,7 +915,7 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int m = m0 + mt * 16 + grp * 4 + rr;
-        if (m < g.M && j < Jtot) atomicAdd(&dwp[(size_t)m * Jp + j], acc[mt][c][rr]);
+        if (m < g.M && j < Jtot) wgrad_out(&dwp[(size_t)split * det_stride + (size_t)m * Jp + j], acc[mt][c][rr], det_stride != 0);
       }
     }
 }

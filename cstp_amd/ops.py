@@ -197,6 +197,13 @@ def set_split_terms(terms: int) -> None:
     check(_lib.load().cstp_gemm_set_split_terms(int(terms)), "cstp_gemm_set_split_terms")
 
 
+def set_deterministic(on: bool) -> None:
+    """Bit-reproducible weight gradients (two-stage split-K instead of f32 atomics; cstp_set_deterministic).  Switch before
+    the first convolution call of a run: the shared workspace is sized by what the library reports at that time."""
+    check(_lib.load().cstp_set_deterministic(1 if on else 0), "cstp_set_deterministic")
+    _ws_cache.clear()
+
+
 def set_conv_tile(x_shape, w_shape, stride, padding, mode: int, tile) -> None:
     """Pin the kernel variant of one convolution geometry and direction (cstp_conv3d_set_tile; mode 0 forward,
     1 backward_data, 2 backward_weight) and keep the autotuner away from it.  For parity tests and A/B timing."""
@@ -318,26 +325,29 @@ class _Conv3d(torch.autograd.Function):
         dy = _req(dy, "conv3d grad_output")
         nbytes = lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc))
         dx = dw = db = None
-        side_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and OVERLAP_WGRAD and x.dim() == 5 \
-            and x.shape[2] * x.shape[3] * x.shape[4] > 1 and w.is_leaf and w.grad is not None
+        # The gradient of a leaf weight whose .grad is a contiguous slice of the flat gradient arena (DIRECT_WGRAD) is ADDED
+        # there by the library itself -- AccumulateGrad folded into the unpacking pass: no temporary, no add kernel -- and
+        # autograd sees None for this input.  With OVERLAP_WGRAD it also runs on a second HIP stream: it feeds nothing
+        # downstream in the backward chain, so the matrix-core-bound weight-gradient kernels execute beside the HBM-bound
+        # BatchNorm backward kernels of the main chain (the arena is joined before anything reads it, _join_side_streams).
+        direct_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and w.is_leaf and w.grad is not None and w.grad.is_contiguous()
+        side_w = direct_w and OVERLAP_WGRAD and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] > 1
+
+        def wgrad_into_arena():
+            wsx = _workspace(x.device, nbytes)
+            if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 2) + _desc_key(desc) not in _tuned:
+                _autotune(lib, desc, 2, x, dy, torch.empty_like(w), wsx)          # (tuning overwrites its output)
+            with _span("conv3d_backward_weight", lambda: _desc_key(desc)):
+                check(lib.cstp_conv3d_backward_weight_acc(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
+                                                          w.grad.data_ptr(), wsx.data_ptr(), wsx.numel(), _ptr(xam), _ptr(dyam),
+                                                          1), "cstp_conv3d_backward_weight")
+
         if side_w:
-            # The weight gradient feeds nothing downstream in the backward chain: it runs on a second HIP stream and adds
-            # itself into the parameter's gradient (a view of the flat gradient arena) there, so the matrix-core-bound
-            # weight-gradient kernels execute beside the HBM-bound BatchNorm backward kernels of the main chain.
-            # (AccumulateGrad sees None for this input; the arena is joined before anything reads it, _join_side_streams.)
             main = torch.cuda.current_stream(x.device)
             side = _side_stream(x.device)
             side.wait_stream(main)                     # dy is complete
             with torch.cuda.stream(side):
-                ws_s = _workspace(x.device, nbytes)
-                dws = torch.empty_like(w)
-                if AUTOTUNE:
-                    _autotune(lib, desc, 2, x, dy, dws, ws_s)
-                with _span("conv3d_backward_weight", lambda: _desc_key(desc)):
-                    check(lib.cstp_conv3d_backward_weight_am(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
-                                                             dws.data_ptr(), ws_s.data_ptr(), ws_s.numel(), _ptr(xam),
-                                                             _ptr(dyam)), "cstp_conv3d_backward_weight")
-                w.grad.add_(dws)
+                wgrad_into_arena()
             x.record_stream(side)
             dy.record_stream(side)
             for cell in (xam, dyam):                   # the cells are read by the side-stream kernels too
@@ -353,7 +363,9 @@ class _Conv3d(torch.autograd.Function):
                 check(lib.cstp_conv3d_backward_data_am(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
                                                        dx.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(dyam)),
                       "cstp_conv3d_backward_data")
-        if ctx.needs_input_grad[1] and not side_w:
+        if direct_w and not side_w:
+            wgrad_into_arena()
+        elif ctx.needs_input_grad[1] and not direct_w:
             dw = torch.empty_like(w)
             if AUTOTUNE:
                 _autotune(lib, desc, 2, x, dy, dw, ws)

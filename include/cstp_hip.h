@@ -84,6 +84,18 @@ int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const
 int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x, const cstp_in_affine* in_affine,
                                    const float* dy, float* dw, void* ws, size_t ws_bytes, const uint32_t* x_absmax,
                                    const uint32_t* dy_absmax);
+/* ... and with accumulate != 0: dw += the weight gradient instead of dw = -- autograd's AccumulateGrad (`.grad += `,
+ * main_byol.py:87 loss.backward()) folded into the unpacking pass, for a `.grad` that lives in the flat gradient arena. */
+int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_desc* desc, const float* x, const cstp_in_affine* in_affine,
+                                    const float* dy, float* dw, void* ws, size_t ws_bytes, const uint32_t* x_absmax,
+                                    const uint32_t* dy_absmax, int32_t accumulate);
+
+/* Deterministic mode, process-wide (also CSTP_DETERMINISTIC=1 in the environment): the weight-gradient kernels reduce their
+ * split-K partial sums through per-split slabs added in a fixed order instead of f32 atomics, so two runs on the same
+ * inputs give bit-identical gradients (slower; for debugging -- the default's summation order varies from run to run, rel 1e-6).
+ * Switch it BEFORE sizing workspaces: cstp_conv3d_workspace_bytes grows by the slab count. */
+int cstp_set_deterministic(int32_t on);
+int32_t cstp_get_deterministic(void);
 
 /* Arithmetic of the split kernels (csrc/igemm_split.h), process-wide: 2 = every fp32 operand scaled by a power of two and
  * split into an f16 PAIR, three f16 MFMA products per fp32 product (default; 22 operand bits, measured at least as close to

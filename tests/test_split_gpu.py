@@ -92,9 +92,20 @@ def test_query_and_set_tile_roundtrip():
     out = (ctypes.c_int32 * 4)()
     _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
     assert list(out) == [144, 128, lib.cstp_gemm_get_split_terms(), 1] and out[2] in (2, 3)
-    ops.set_split_terms(3)
+    ops.set_split_terms(3)              # every arithmetic has its own class of pinned / tuned tiles
     _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
-    assert out[2] == 3 and lib.cstp_gemm_get_split_terms() == 3
+    assert out[2] == 0 and lib.cstp_gemm_get_split_terms() == 3          # nothing pinned in the bf16-triple class yet
+    ops.set_conv_tile(xs, (k, xs[1]) + ks, st, pd, 0, (1, 9, 0, 0))
+    _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
+    assert list(out) == [144, 128, 3, 1]
+    got = (ctypes.c_int32 * 4)()
+    _lib.check(lib.cstp_conv3d_get_tile(ctypes.byref(desc), 0, got), "get")
+    assert list(got) == [1, 9, 1, 1]                                      # set_tile's encoding, replayable
+    ops.set_split_terms(1)              # native f32 MFMA only
+    _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
+    assert out[2] == 0 and lib.cstp_gemm_get_split_terms() == 1
+    _lib.check(lib.cstp_conv3d_get_tile(ctypes.byref(desc), 0, got), "get")
+    assert got[0] == -1                                                   # untuned in this class
     ops.set_split_terms(0)
     with pytest.raises(_lib.CstpError):
         ops.set_split_terms(4)
@@ -274,3 +285,62 @@ def test_patch_tile_is_refused_where_the_kernel_does_not_apply():
     finally:
         ops.set_split_terms(0)
         del GEOMS["_patch"]
+
+
+# ---- weight gradient: accumulation into the caller's buffer, and the deterministic (two-stage split-K) mode -------------------
+def _wgrad_call(lib, ops, desc, x, dy, dw, accumulate):
+    import ctypes
+    ws = torch.empty(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device="cuda")
+    ops.check(lib.cstp_conv3d_backward_weight_acc(torch.cuda.current_stream().cuda_stream, ctypes.byref(desc), x.data_ptr(), None,
+                                                  dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), None, None, accumulate),
+              "cstp_conv3d_backward_weight_acc")
+
+
+@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (0, 3, 4, 0)], ids=["split", "native"])
+def test_weight_gradient_accumulate_flag(tile):
+    from cstp_amd import _lib, ops
+    lib = _lib.load()
+    xs, k, ks, st, pd = GEOMS["S1"]
+    x = _rand(xs, 11).float().cuda()
+    w = (_rand((k, xs[1]) + ks, 12) * 0.2).double().requires_grad_(True)
+    y = F.conv3d(x.double().cpu(), w, None, st, pd)
+    dy = _rand(y.shape, 13)
+    y.backward(dy)
+    ops.set_conv_tile(xs, w.shape, st, pd, 2, tile)
+    desc = ops._desc(xs, tuple(w.shape), st, pd)
+    base = torch.full(w.shape, 0.75, device="cuda")
+    dw = base.clone()
+    _wgrad_call(lib, ops, desc, x, dy.float().cuda(), dw, 1)
+    assert rel_err(dw - base, w.grad) < TOL                      # dw += gradient
+    _wgrad_call(lib, ops, desc, x, dy.float().cuda(), dw, 0)
+    assert rel_err(dw, w.grad) < TOL                             # dw = gradient
+
+
+@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (1, 4, 16, 0), (0, 3, 4, 0), (0, 9, 8, 0)], ids=["split9", "split4", "native3", "native144"])
+def test_deterministic_weight_gradient_is_bit_reproducible(tile):
+    """CSTP_DETERMINISTIC / cstp_set_deterministic: per-split slabs summed in a fixed order instead of f32 atomics -- the same
+    inputs give the same bits, and the result keeps the parity bar."""
+    from cstp_amd import _lib, ops
+    lib = _lib.load()
+    xs, k, ks, st, pd = (4, 64, 8, 28, 28), 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    x = _rand(xs, 21).float().cuda()
+    w = (_rand((k, xs[1]) + ks, 22) * 0.2).double().requires_grad_(True)
+    y = F.conv3d(x.double().cpu(), w, None, st, pd)
+    dy = _rand(y.shape, 23)
+    y.backward(dy)
+    dyg = dy.float().cuda()
+    ops.set_conv_tile(xs, w.shape, st, pd, 2, tile)
+    desc = ops._desc(xs, tuple(w.shape), st, pd)
+    ops.set_deterministic(True)
+    try:
+        assert lib.cstp_get_deterministic() == 1
+        runs = []
+        for _ in range(3):
+            dw = torch.empty(w.shape, device="cuda")
+            _wgrad_call(lib, ops, desc, x, dyg, dw, 0)
+            runs.append(dw)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        assert rel_err(runs[0], w.grad) < TOL
+    finally:
+        ops.set_deterministic(False)
+    assert lib.cstp_get_deterministic() == 0
