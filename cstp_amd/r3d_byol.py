@@ -1,5 +1,5 @@
 """3D-ResNet-BYOL for MI355X -- host-side mirror of /root/reference/models/BE/r3d_byol.py (the backbone swap of
-BASELINE.json configs[4]), BasicBlock depths 10 / 18 / 34.
+BASELINE.json configs[4]): BasicBlock depths 10 / 18 / 34 and the Bottleneck depth 50 (/ 101 / 152).
 
 Mirrors (same class names, attribute names, state-dict keys, argument meaning and error behaviour):
   conv3x3x3 :45-53, BasicBlock :69-97, ResNet :139-206 (7x7x7 stem stride (1,2,2) -> BN -> ReLU -> MaxPool3d(3, 2, 1) ->
@@ -8,9 +8,18 @@ Mirrors (same class names, attribute names, state-dict keys, argument meaning an
 Differences from the R(2+1)D wrapper that the reference makes and this file keeps: the encoder has no projector (the
 predictor and the target comparison act on the 512-d features), target_net is a deepcopy of online_net (identical initial
 weights), the pretext heads are plain Linear layers with 4-way playback-rate / rotation outputs, the fine-tune BatchNorm is
-called ``classify_bn``.  The Bottleneck depths (50+) are shape-broken in the reference (r3d_byol.py:204: ``view(-1, 512)`` of
-2048 features quadruples the batch) and are refused here; shortcut type 'A' (:56-66) builds a CPU tensor inside forward and
-is refused too -- 'B' (1x1x1 conv + BN) is the default (opts.py: --sc_type B).
+called ``classify_bn``.  Shortcut type 'A' (:56-66) builds a CPU tensor inside forward and is refused -- 'B' (1x1x1 conv + BN)
+is the default (opts.py: --sc_type B).
+
+Bottleneck depths (configs[4] names 3D-ResNet-50).  The reference's Bottleneck BACKBONE (:100-137, ResNet.__init__ :139-191) is
+sound and is mirrored module for module (pinned: tests/golden/r3d_50_backbone.npz drives the reference's layers up to the
+average pool).  Its WRAPPER cannot run at these depths: ``x.view(-1, 512)`` (:204) turns the [B, 2048] pooled features into
+[4B, 512], and Projector / Predictor / the four heads / classify are hard-wired to 512 inputs (:212,226,249-252,262), so the
+logits come out with 4B rows against B labels.  SPEC of the corrected wrapper implemented here (PARITY-UNPINNED -- the
+reference has nothing to compare with): feature width F = 512 x block.expansion replaces every literal 512 that means "the
+encoder's output": ``view(-1, F)``; Predictor Linear(F, 4096) -> BN1d -> ReLU -> Linear(4096, F) (BYOL compares the prediction
+with the F-wide target feature); overlap_spa / overlap_tem Linear(2F, 5); pb_cls / rot_cls Linear(F, 4); classify_bn
+BatchNorm1d(F); classify Linear(F, n_classes).  For F = 512 this is the reference, key for key.
 
 All arithmetic runs in the HIP kernels of libcstp_hip.so through cstp_amd.ops: the 3x3x3 convolutions are the 27-tap case of the
 implicit-GEMM kernels, the stem the 343-tap / 3-channel case, MaxPool3d has its own kernel pair.
@@ -27,6 +36,7 @@ from .r21d_byol import (OVERLAP_TARGET_FORWARD, BatchNorm1d, BatchNorm3d, ByolBa
                         get_fine_tuning_parameters)
 
 LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+BOTTLENECK_LAYERS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}     # resnet50/101/152 :458-479
 
 
 def conv3x3x3(in_planes, out_planes, stride=1):
@@ -63,6 +73,32 @@ class BasicBlock(nn.Module):
         return self.bn2(out, residual=residual, relu=True, groups=groups)  # relu(bn2(.) + residual)  :88-95, one kernel
 
 
+class Bottleneck(nn.Module):
+    """1x1x1 -> BN -> ReLU -> 3x3x3 (stride) -> BN -> ReLU -> 1x1x1 (x4 channels) -> BN -> (+ residual) -> ReLU
+    (r3d_byol.py:100-137).  The 1x1x1 convolutions are the one-tap case of the implicit-GEMM kernels (pure channel GEMMs: the
+    MFMA 1x1 path north_star names); BN + residual + ReLU is one kernel."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv3d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm3d(planes)
+        self.conv2 = Conv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm3d(planes)
+        self.conv3 = Conv3d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm3d(planes * 4)
+        self.relu = ReLU()
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x, groups=1):
+        out = self.bn1(self.conv1(x), relu=True, groups=groups)
+        out = self.bn2(self.conv2(out), relu=True, groups=groups)
+        out = self.conv3(out)
+        residual = x if self.downsample is None else self.downsample(x, groups)
+        return self.bn3(out, residual=residual, relu=True, groups=groups)
+
+
 class _Stage(nn.Sequential):
     def forward(self, x, groups=1):
         for block in self:
@@ -77,6 +113,7 @@ class ResNet(nn.Module):
             raise NotImplementedError("shortcut type %r: cstp_amd implements the reference default 'B' (1x1x1 conv + BN); 'A' "
                                       "allocates a CPU tensor inside forward (r3d_byol.py:56-66)" % (shortcut_type,))
         self.inplanes = 64
+        self.feat_dim = 512 * block.expansion
         self.conv1 = Conv3d(3, 64, kernel_size=7, stride=(1, 2, 2), padding=(3, 3, 3), bias=False)
         self.bn1 = BatchNorm3d(64)
         self.relu = ReLU()
@@ -107,14 +144,15 @@ class ResNet(nn.Module):
         x = self.layer2(x, groups)
         x = self.layer3(x, groups)
         x = self.layer4(x, groups)
-        return ops.global_avg_pool(x)      # AdaptiveAvgPool3d(1) + view(-1, 512)
+        return ops.global_avg_pool(x)      # AdaptiveAvgPool3d(1) + view(-1, 512) -- view(-1, feat_dim) at the Bottleneck depths
 
 
 def _resnet(depth, **kwargs):
-    if int(depth) not in LAYERS:
-        raise ValueError("r3d_byol supports the BasicBlock depths %s, got %r (the reference's Bottleneck depths are "
-                         "shape-broken, r3d_byol.py:204)" % (sorted(LAYERS), depth))
-    return ResNet(BasicBlock, LAYERS[int(depth)], **kwargs)
+    if int(depth) in LAYERS:
+        return ResNet(BasicBlock, LAYERS[int(depth)], **kwargs)
+    if int(depth) in BOTTLENECK_LAYERS:
+        return ResNet(Bottleneck, BOTTLENECK_LAYERS[int(depth)], **kwargs)
+    raise ValueError("r3d_byol supports --model_depth %s, got %r" % (sorted(LAYERS) + sorted(BOTTLENECK_LAYERS), depth))
 
 
 def resnet10(**kwargs):
@@ -129,6 +167,10 @@ def resnet34(**kwargs):
     return _resnet(34, **kwargs)
 
 
+def resnet50(**kwargs):
+    return _resnet(50, **kwargs)
+
+
 class R3DBYOL(ByolBase):
     """forward(x1, x2, o_type='loss_com') -> (loss_byol, (pred_spa, pred_tem, pred_pb_1, pred_pb_2, pred_rot_1, pred_rot_2))
     with [B,5], [B,5], [B,4] x4 logits (r3d_byol.py:381-405)."""
@@ -141,19 +183,21 @@ class R3DBYOL(ByolBase):
         if pretrain:
             self.momentum = momentum
             self.online_net = _resnet(opts.model_depth, **kw)
+            f = self.online_net.feat_dim         # 512 for the BasicBlock depths (= the reference); 2048 at depth 50 (spec above)
             self.target_net = copy.deepcopy(self.online_net)
-            self.predictor = Predictor(dim=512, prediction_size=512, prediction_hidden_size=4096)
+            self.predictor = Predictor(dim=f, prediction_size=f, prediction_hidden_size=4096)
             self._set_grad(self.target_net, False)
-            self.overlap_spa = Linear(1024, 5)
-            self.overlap_tem = Linear(1024, 5)
-            self.pb_cls = Linear(512, 4)
-            self.rot_cls = Linear(512, 4)
+            self.overlap_spa = Linear(2 * f, 5)
+            self.overlap_tem = Linear(2 * f, 5)
+            self.pb_cls = Linear(f, 4)
+            self.rot_cls = Linear(f, 4)
         else:
             self.online_net = _resnet(opts.model_depth, **kw)
+            f = self.online_net.feat_dim
             self.cls_bn = cls_bn
             if self.cls_bn:
-                self.classify_bn = BatchNorm1d(512)
-            self.classify = Linear(512, opts.n_classes)
+                self.classify_bn = BatchNorm1d(f)
+            self.classify = Linear(f, opts.n_classes)
         self._glorot_all((Linear, Conv3d, BatchNorm1d, BatchNorm3d))   # :265-273 (the deep-copied target is re-drawn too)
         self._arenas = None
 

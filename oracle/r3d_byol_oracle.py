@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the 3D-ResNet-BYOL wrapper (BasicBlock depths 10 / 18 / 34).
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the 3D-ResNet-BYOL wrapper (BasicBlock depths 10 / 18 / 34; Bottleneck depth 50).
 
 Functional restatement (flat ``dict`` of tensors keyed like the reference ``state_dict``) executed with stock PyTorch CPU ops;
 pinned against golden vectors captured from the reference itself (``tests/golden/make_golden_r3d.py`` imports
@@ -13,6 +13,13 @@ What each function follows (paths relative to /root/reference/models/BE/r3d_byol
 * ``model_forward``                   R3DBYOL.forward, o_type == 'loss_com' :381-405
 * ``train_step``                      main_byol.py:60-91 with this wrapper's 4-way playback / rotation heads
 * ``ft_forward``                      :420-428 ('ft_fc' / 'ft_all' / 'test'), :429-432 ('scratch')
+* ``bottleneck_block``                Bottleneck.forward :117-137 (1x1x1 -> 3x3x3 stride s -> 1x1x1 x4, BN after each)
+
+Depth 50 (BASELINE configs[4]): the reference's BACKBONE modules (conv1 .. layer4, avgpool) are sound and pin this file's
+``encoder_forward`` through ``tests/golden/r3d_50_backbone.npz``; its WRAPPER is not -- ``view(-1, 512)`` of the 2048 pooled
+features (:204) quadruples the batch, and Predictor / heads are hard-wired to 512 inputs (:212,226,249-252) -- so for depth 50
+this file implements the corrected wrapper spec (feature width F = 512 x expansion everywhere the reference writes 512:
+view(-1, F), Predictor F -> 4096 -> F, heads on F / 2F inputs, classify_bn(F), classify(F)), which is PARITY-UNPINNED.
 """
 from __future__ import annotations
 
@@ -24,7 +31,32 @@ import torch.nn.functional as F
 
 from . import r21d_byol_oracle as base
 
-LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3)}
+EXPANSION = {10: 1, 18: 1, 34: 1, 50: 4}
+_exp = {"v": 1}          # expansion of the spec / forward being built (set by for_depth)
+
+
+def for_depth(depth: int):
+    """Select the block type for the spec / forward functions below; returns the layer sizes."""
+    _exp["v"] = EXPANSION[int(depth)]
+    return LAYERS[int(depth)]
+
+
+def feat_dim() -> int:
+    return 512 * _exp["v"]
+
+
+def _bottleneck_spec(prefix: str, cin: int, planes: int, downsample: bool):
+    spec = [(prefix + ".conv1.weight", (planes, cin, 1, 1, 1), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn1", planes)
+    spec += [(prefix + ".conv2.weight", (planes, planes, 3, 3, 3), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn2", planes)
+    spec += [(prefix + ".conv3.weight", (planes * 4, planes, 1, 1, 1), "conv_w")]
+    spec += base._bn_spec(prefix + ".bn3", planes * 4)
+    if downsample:
+        spec += [(prefix + ".downsample.0.weight", (planes * 4, cin, 1, 1, 1), "conv_w")]
+        spec += base._bn_spec(prefix + ".downsample.1", planes * 4)
+    return spec
 
 
 def _block_spec(prefix: str, cin: int, cout: int, downsample: bool):
@@ -42,26 +74,31 @@ def encoder_spec(prefix: str, layers: Sequence[int]):
     spec = [(prefix + ".conv1.weight", (64, 3, 7, 7, 7), "conv_w")]
     spec += base._bn_spec(prefix + ".bn1", 64)
     cin = 64
+    e = _exp["v"]
     for li, (cout, n) in enumerate(zip((64, 128, 256, 512), layers)):
         for bi in range(n):
-            ds = bi == 0 and (li > 0 or cin != cout)
-            spec += _block_spec("%s.layer%d.%d" % (prefix, li + 1, bi), cin, cout, ds)
-            cin = cout
+            ds = bi == 0 and (li > 0 or cin != cout * e)       # ResNet._make_layer :173
+            if e == 1:
+                spec += _block_spec("%s.layer%d.%d" % (prefix, li + 1, bi), cin, cout, ds)
+            else:
+                spec += _bottleneck_spec("%s.layer%d.%d" % (prefix, li + 1, bi), cin, cout, ds)
+            cin = cout * e
     return spec
 
 
 def model_spec(layers: Sequence[int]):
     spec = encoder_spec("online_net", layers) + encoder_spec("target_net", layers)
-    spec += base._mlp_spec("predictor.net", 512, 4096, 512)
-    for name, din, dout in (("overlap_spa", 1024, 5), ("overlap_tem", 1024, 5), ("pb_cls", 512, 4), ("rot_cls", 512, 4)):
+    f = feat_dim()
+    spec += base._mlp_spec("predictor.net", f, 4096, f)
+    for name, din, dout in (("overlap_spa", 2 * f, 5), ("overlap_tem", 2 * f, 5), ("pb_cls", f, 4), ("rot_cls", f, 4)):
         spec += [(name + ".weight", (dout, din), "lin_w"), (name + ".bias", (dout,), "lin_b")]
     return spec
 
 
 def ft_spec(layers: Sequence[int], num_classes: int):
     spec = encoder_spec("online_net", layers)
-    spec += base._bn_spec("classify_bn", 512)
-    spec += [("classify.weight", (num_classes, 512), "lin_w"), ("classify.bias", (num_classes,), "lin_b")]
+    spec += base._bn_spec("classify_bn", feat_dim())
+    spec += [("classify.weight", (num_classes, feat_dim()), "lin_w"), ("classify.bias", (num_classes,), "lin_b")]
     return spec
 
 
@@ -99,14 +136,29 @@ def basic_block(sd, prefix, x, stride, training=True):
     return F.relu(out + residual)
 
 
+def bottleneck_block(sd, prefix, x, stride, training=True):
+    out = F.conv3d(x, sd[prefix + ".conv1.weight"], None, 1, 0)
+    out = F.relu(base._bn(sd, prefix + ".bn1", out, training))
+    out = F.conv3d(out, sd[prefix + ".conv2.weight"], None, stride, 1)
+    out = F.relu(base._bn(sd, prefix + ".bn2", out, training))
+    out = F.conv3d(out, sd[prefix + ".conv3.weight"], None, 1, 0)
+    out = base._bn(sd, prefix + ".bn3", out, training)
+    residual = x
+    if (prefix + ".downsample.0.weight") in sd:
+        residual = F.conv3d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
+        residual = base._bn(sd, prefix + ".downsample.1", residual, training)
+    return F.relu(out + residual)
+
+
 def encoder_forward(sd, prefix, x, layers, training=True):
     x = F.conv3d(x, sd[prefix + ".conv1.weight"], None, (1, 2, 2), (3, 3, 3))
     x = F.relu(base._bn(sd, prefix + ".bn1", x, training))
     x = F.max_pool3d(x, 3, 2, 1)
     for li, n in enumerate(layers):
         for bi in range(n):
-            x = basic_block(sd, "%s.layer%d.%d" % (prefix, li + 1, bi), x, 2 if (bi == 0 and li > 0) else 1, training)
-    return x.mean(dim=(2, 3, 4)).view(-1, 512)
+            blk = bottleneck_block if (prefix + ".layer1.0.conv3.weight") in sd else basic_block
+            x = blk(sd, "%s.layer%d.%d" % (prefix, li + 1, bi), x, 2 if (bi == 0 and li > 0) else 1, training)
+    return x.mean(dim=(2, 3, 4)).flatten(1)        # view(-1, 512) for the BasicBlock depths; view(-1, 2048) at depth 50 (spec)
 
 
 def ema_update(sd, layers, m: float = base.EMA_MOMENTUM):

@@ -45,7 +45,7 @@ def ref_opts(depth, t, hw, k=101):
 
 def build(depth, t, hw, dtype):
     m = ref_model.R3DBYOL(pretrain=True, opts=ref_opts(depth, t, hw))
-    sd = r3d.closed_form_state(r3d.model_spec(r3d.LAYERS[depth]), torch.float64)
+    sd = r3d.closed_form_state(r3d.model_spec(r3d.for_depth(depth)), torch.float64)
     res = m.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     assert list(m.state_dict().keys()) == list(sd.keys()), "state-dict order differs from oracle spec"
@@ -110,7 +110,7 @@ def run_config(name):
         out["fwd." + k] = v.numpy().astype(np.float32)
     # fine-tune / test wrapper on the same encoder weights: train-mode and eval-mode logits (r3d_byol.py:420-428)
     ft = ref_model.R3DBYOL(pretrain=False, cls_bn=True, opts=ref_opts(depth, t, hw, k=11))
-    sdf = r3d.closed_form_state(r3d.ft_spec(r3d.LAYERS[depth], 11), torch.float64)
+    sdf = r3d.closed_form_state(r3d.ft_spec(r3d.for_depth(depth), 11), torch.float64)
     res = ft.load_state_dict(sdf, strict=True)
     assert not res.missing_keys and not res.unexpected_keys and list(ft.state_dict().keys()) == list(sdf.keys())
     ft = ft.to(dtype).train()
@@ -123,7 +123,48 @@ def run_config(name):
     print("wrote", name)
 
 
+def run_backbone50():
+    """Depth 50: the reference WRAPPER is shape-broken (view(-1, 512) of 2048 features, r3d_byol.py:204), its BACKBONE
+    modules are not.  Drive ResNet(Bottleneck, [3, 4, 6, 3]) layer by layer up to the average pool (the statements of
+    ResNet.forward :193-203 without the broken view) in train mode, fp64: pooled features of two clip batches, and the
+    per-tensor gradient norms of  sum(features * c)  for a closed-form c -- pins Bottleneck forward and backward."""
+    b, t, hw = 4, 8, 64
+    net = ref_model.resnet50(sample_size=hw, sample_duration=t, shortcut_type="B", num_classes=101)
+    layers = r3d.for_depth(50)
+    sd = r3d.closed_form_state(r3d.encoder_spec("online_net", layers), torch.float64)
+    sd = {k[len("online_net."):]: v for k, v in sd.items()}
+    res = net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys and list(net.state_dict().keys()) == list(sd.keys())
+    net = net.double().train()
+
+    def backbone(x):
+        x = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        x = net.layer4(net.layer3(net.layer2(net.layer1(x))))
+        return net.avgpool(x).flatten(1)
+
+    x1, x2, _ = orc.closed_form_clips(b, t, hw, dtype=torch.float64)
+    out = {"meta": np.array([50, b, t, hw, 0], dtype=np.int64)}
+    f1 = backbone(x1)
+    c = orc.hash_uniform(f1.numel(), 4242).reshape(f1.shape)
+    (f1 * c).sum().backward()
+    names = [k for k, _ in net.named_parameters()]
+    out["feat_1"] = f1.detach().numpy().astype(np.float32)
+    out["grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()])
+    out["param_keys"] = np.array(names)
+    out["state_keys"] = np.array(list(net.state_dict().keys()))
+    out["state_cs_after_fwd"] = checksums(net.state_dict().items())           # BN running statistics moved once
+    with torch.no_grad():
+        out["feat_2"] = backbone(x2).numpy().astype(np.float32)
+        net.eval()
+        out["feat_eval"] = backbone(x1).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "r3d_50_backbone.npz"), **out)
+    print("wrote r3d_50_backbone", out["feat_1"].shape)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for c in (sys.argv[1:] or list(CONFIGS)):
-        run_config(c)
+    for c in (sys.argv[1:] or list(CONFIGS) + ["r3d_50_backbone"]):
+        if c == "r3d_50_backbone":
+            run_backbone50()
+        else:
+            run_config(c)

@@ -52,7 +52,7 @@ def test_r3d_hip_matches_reference_golden(name):
     from oracle import r3d_byol_oracle as r3d
     g = load(name)
     depth, b, t, hw, steps = [int(v) for v in g["meta"]]
-    layers = r3d.LAYERS[depth]
+    layers = r3d.for_depth(depth)
     sd = r3d.closed_form_state(r3d.model_spec(layers), torch.float32)
     x1, x2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
     lab = {k: v.cuda() for k, v in r3d.closed_form_labels(b).items()}
@@ -169,3 +169,72 @@ def test_r3d_finetune_and_test_drivers(tmp_path, capsys):
     opts = parse_opts(common + ["--task", "test", "--t_ft_task", "scratch"])
     acc = load("test").run(opts)
     assert 0.0 <= acc <= 1.0 and "Video accuracy" in capsys.readouterr().out
+
+
+def test_r3d_50_bottleneck_backbone_matches_reference_modules_and_corrected_wrapper_matches_oracle():
+    """BASELINE configs[4] names 3D-ResNet-50.  (1) The Bottleneck BACKBONE on the HIP kernels against the reference's own layers
+    driven up to the average pool in fp64 (tests/golden/r3d_50_backbone.npz): pooled 2048-d features of two clip batches, the
+    per-tensor gradient norms of sum(features * c), the BN running statistics, and the eval-mode features.  (2) The WRAPPER at
+    this depth follows the corrected spec of cstp_amd/r3d_byol.py (the reference's is shape-broken, r3d_byol.py:204) and is
+    parity-UNPINNED: one optimisation step of the product's PretrainStep is put against the CPU oracle of the same spec."""
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r3d_byol import R3DBYOL
+    from cstp_amd.train import PretrainStep
+    from oracle import r21d_byol_oracle as orc
+    from oracle import r3d_byol_oracle as r3d
+    g = load("r3d_50_backbone")
+    depth, b, t, hw, _ = [int(v) for v in g["meta"]]
+    layers = r3d.for_depth(depth)
+    try:
+        esd = r3d.closed_form_state(r3d.encoder_spec("online_net", layers), torch.float32)
+        net = R3DBYOL(pretrain=False, cls_bn=True, opts=_opts(depth, t, hw, 11)).online_net
+        res = net.load_state_dict({k[len("online_net."):]: v for k, v in esd.items()}, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        net.cuda().train()
+        x1, x2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
+        x1d, x2d = x1.cuda(), x2.cuda()
+        f1 = net(x1d)
+        assert tuple(f1.shape) == (b, 2048)
+        c = orc.hash_uniform(f1.numel(), 4242).reshape(f1.shape).float().cuda()
+        (f1 * c).sum().backward()
+        assert rel(f1.detach().cpu().numpy(), g["feat_1"]) < 3e-4          # 53 conv + BN layers: the R34-class output bar
+        gn = np.array([float(p.grad.norm()) for _, p in net.named_parameters()])
+        assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+        assert rel(gn, g["grad_norms"]) < 3e-2
+        msd = net.state_dict()
+        cs = np.array([[float(msd[str(k)].double().sum()), float(msd[str(k)].double().abs().sum())] for k in g["state_keys"]])
+        assert cs_err(cs, g["state_cs_after_fwd"]) < 1e-4
+        with torch.no_grad():
+            assert rel(net(x2d).cpu().numpy(), g["feat_2"]) < 3e-4
+            net.eval()
+            assert rel(net(x1d).cpu().numpy(), g["feat_eval"]) < 2e-3
+
+        # ---- the corrected wrapper (F = 2048), one full step vs the oracle of the same spec, on a smaller clip
+        bb, tt, hh = 4, 4, 32
+        sd = r3d.closed_form_state(r3d.model_spec(layers), torch.float32)
+        y1, y2, _ = orc.closed_form_clips(bb, tt, hh, torch.float32)
+        labels = r3d.closed_form_labels(bb)
+        w = (0.1, 1.0, 1.0, 1.0, 1.0)
+        osd = {k: v.clone() for k, v in sd.items()}
+        info = r3d.train_step(osd, {}, y1, y2, labels, layers, 0.05, 0.9, 5e-4, w, True)
+        model = R3DBYOL(pretrain=True, opts=_opts(depth, tt, hh))
+        res = model.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        model.cuda()
+        arenas = model.flatten_parameters()
+        model.train()
+        opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=arenas)
+        step = PretrainStep(model, opt, w, clip_grad_norm=True)
+        lab = {k: v.cuda() for k, v in labels.items()}
+        out = step(y1.cuda(), y2.cuda(), lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+        assert tuple(out.logits[0].shape) == (bb, 5) and tuple(out.logits[2].shape) == (bb, 4)     # B rows, not 4B
+        assert rel(float(out.loss_byol), float(info["loss_byol"])) < 5e-4
+        assert rel(float(out.loss_total), float(info["loss_total"])) < 5e-4
+        assert rel(torch.stack([l.cpu() for l in out.logits[:2]]).numpy(), torch.stack(info["logits"][:2]).numpy()) < 2e-3
+        assert rel(float(out.grad_norm), float(info["grad_norm"])) < 3e-2
+        msd = model.state_dict()
+        for k in ("online_net.layer4.2.bn3.running_var", "target_net.layer1.0.conv3.weight", "predictor.net.3.weight",
+                  "overlap_spa.weight"):
+            assert rel(msd[k].cpu().numpy(), osd[k].detach().numpy()) < 2e-3, k
+    finally:
+        r3d.for_depth(18)

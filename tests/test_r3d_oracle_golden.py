@@ -29,7 +29,7 @@ def checksums(sd, keys):
 def test_r3d_oracle_matches_reference_golden(name):
     g = load(name)
     depth, b, t, hw, steps = [int(v) for v in g["meta"]]
-    layers = r3d.LAYERS[depth]
+    layers = r3d.for_depth(depth)
     spec = r3d.model_spec(layers)
     keys = [str(k) for k in g["state_keys"]]
     pkeys = [str(k) for k in g["param_keys"]]
@@ -85,7 +85,7 @@ def test_r3d_module_state_dict_contract_and_errors():
     assert not torch.equal(m.online_net.conv1.weight, m.target_net.conv1.weight)
     assert all(not p.requires_grad for p in m.target_net.parameters())
     with pytest.raises(ValueError):
-        R3DBYOL(pretrain=True, opts=_opts(50))
+        R3DBYOL(pretrain=True, opts=_opts(26))
     o = _opts(18)
     o.sc_type = "A"
     with pytest.raises(NotImplementedError):
@@ -93,3 +93,42 @@ def test_r3d_module_state_dict_contract_and_errors():
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1), torch.zeros(1), o_type="r_byol")
     assert m(torch.zeros(1), torch.zeros(1), o_type="nonsense") is None
+
+
+def test_r3d_50_backbone_oracle_matches_reference_modules():
+    """Depth 50: the reference's Bottleneck BACKBONE driven layer by layer (its wrapper is shape-broken, r3d_byol.py:204) pins the
+    oracle's encoder forward and backward; the wrapper around it follows the corrected spec and is parity-unpinned."""
+    g = load("r3d_50_backbone")
+    depth, b, t, hw, _ = [int(v) for v in g["meta"]]
+    layers = r3d.for_depth(depth)
+    try:
+        spec = r3d.encoder_spec("online_net", layers)
+        keys = [str(k) for k in g["state_keys"]]
+        assert [k[len("online_net."):] for k, _, _ in spec] == keys
+        sd = r3d.closed_form_state(spec, torch.float32)
+        pkeys = ["online_net." + str(k) for k in g["param_keys"]]
+        for k in pkeys:
+            sd[k].requires_grad_(True)
+        x1, x2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
+        f1 = r3d.encoder_forward(sd, "online_net", x1, layers, True)
+        assert f1.shape == (b, 2048) and r3d.feat_dim() == 2048
+        c = orc.hash_uniform(f1.numel(), 4242).reshape(f1.shape).float()
+        grads = torch.autograd.grad((f1 * c).sum(), [sd[k] for k in pkeys])
+        assert rel(f1.detach().numpy(), g["feat_1"]) < 1e-4
+        assert rel(np.array([float(gr.norm()) for gr in grads]), g["grad_norms"]) < 2e-2
+        with torch.no_grad():
+            assert cs_err(checksums(sd, ["online_net." + k for k in keys]), g["state_cs_after_fwd"]) < 1e-4
+            assert rel(r3d.encoder_forward(sd, "online_net", x2, layers, True).numpy(), g["feat_2"]) < 1e-4
+            assert rel(r3d.encoder_forward(sd, "online_net", x1, layers, False).numpy(), g["feat_eval"]) < 2e-3
+        # the module mirror: Bottleneck keys in the reference's order; head widths follow the corrected spec (F = 2048)
+        from cstp_amd.r3d_byol import R3DBYOL
+        m = R3DBYOL(pretrain=True, opts=_opts(50))
+        assert [k for k in m.state_dict() if k.startswith("online_net.")] == ["online_net." + k for k in keys]
+        assert [k for k, _, _ in r3d.model_spec(layers)] == list(m.state_dict().keys())
+        assert m.predictor.net[0].weight.shape == (4096, 2048) and m.predictor.net[3].weight.shape == (2048, 4096)
+        assert m.overlap_spa.weight.shape == (5, 4096) and m.pb_cls.weight.shape == (4, 2048)
+        ft = R3DBYOL(pretrain=False, cls_bn=True, opts=_opts(50, 11))
+        assert ft.classify.weight.shape == (11, 2048) and ft.classify_bn.weight.shape == (2048,)
+        assert [k for k, _, _ in r3d.ft_spec(layers, 11)] == list(ft.state_dict().keys())
+    finally:
+        r3d.for_depth(18)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Pre-training throughput of the 3D-ResNet-BYOL wrapper on one MI355X (synthetic clips resident in HBM): the per-GPU share of
 BASELINE.json configs[4] (B = 32 over 8 GPUs -> 4 clip pairs per GPU, 3x16x224x224) on the BasicBlock depths the reference can
-actually run (10 / 18 / 34; its depth-50 wrapper is shape-broken), fp32.
+can run (10 / 18 / 34) and on the Bottleneck depth 50 that configs[4] names (corrected wrapper: cstp_amd/r3d_byol.py), fp32 storage.
 
     python tools/bench_r3d.py --depth 18 --batch 4 --size 224 --steps 10
 
