@@ -845,8 +845,14 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
   if (p.f_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.f_t.mt) && patch_geom_ok(d))) p.f_t = Tile{2, 1, 0, 1, 0};
-  if (p.f_t.sp == 1 && (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
+  // (the 3-channel stems run a split tile in its straddle mode: zero-padded input copy, per-k offset table, f16 pair only)
+  const bool stem_split_ok = p.f_straddle && p.f_t.sp == 1 && p.f_t.wm == 1 && (p.f_t.mt >= 4 && p.f_t.mt <= 6) &&
+                             split_planes() == 2 && p.ntaps * d.c <= STR_KMAX - 16 &&
+                             (size_t)d.n * d.c * (d.d + 2 * d.pt) * (d.h + 2 * d.ph) * (d.w + 2 * d.pw) < (1ull << 29);
+  if (p.f_t.sp == 1 && !stem_split_ok &&
+      (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
     p.f_t = Tile{2, 1, 0, 1, 0};
+  if (p.f_t.sp == 1 && stem_split_ok && (!y_small || native_only())) p.f_t = Tile{2, 1, 0, 1, 0};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
   p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
@@ -933,6 +939,8 @@ static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
     if (pf > f) f = pf;
     if (pg > g) g = pg;
   }
+  // the stems' split path keeps a zero-padded copy of the input behind the packed weights
+  if (d.c < 8) f = align_up(f, 256) + align_up((size_t)d.n * d.c * (d.d + 2 * d.pt) * (d.h + 2 * d.ph) * (d.w + 2 * d.pw) * 4, 256);
   size_t w = align_up((size_t)d.k * p.w_Jp * sizeof(float), 256) * (deterministic() ? DET_MAX_SPLITS : 1);
   size_t m = f > g ? f : g;
   if (w > m) m = w;
@@ -1050,6 +1058,37 @@ static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, con
                           src_absmax != nullptr ? src_absmax : cells);
 }
 
+// the 3-channel stems on the f16-pair split kernel (igemm_k1s<.., STR = true>): zero-padded input copy (+ its absmax as a
+// by-product), weights packed in k = tap * c_in + c order, per-k offset table inside the kernel
+static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, const float* w, const float* x,
+                         const float* bias, float* y, void* ws, size_t main_bytes) {
+  const int Dq = d.d + 2 * d.pt, Hq = d.h + 2 * d.ph, Wq = d.w + 2 * d.pw;
+  const int kreal = p.ntaps * d.c, Kp = (int)align_up(kreal, 16);
+  const int bm = 16 * tl.mt, Mp = cdiv(d.k, bm) * bm;
+  const size_t packed = align_up((size_t)Kp * ((size_t)d.k + 160) * 6, 256);
+  float* xp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + packed);
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
+  float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
+  hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
+                     d.k, d.c, p.ntaps, d.c, Mp, Kp / 16, 0);
+  const size_t np = (size_t)d.n * d.c * Dq * Hq * Wq;
+  hipLaunchKernelGGL(pad_input_kernel, dim3(pack_grid(np / 4)), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph,
+                     d.pw);
+  Geom g;
+  g.Cs = d.c; g.Ds = Dq; g.Hs = Hq; g.Ws = Wq;
+  g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;
+  g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = 0; g.ph = 0; g.pw = 0;
+  g.Cp = d.c; g.M = d.k; g.Mp = Mp; g.Ktot = Kp;
+  const int npos = d.n * p.Do * p.Ho * p.Wo;
+  const int ntx = cdiv(npos, 128), ntm = cdiv(d.k, bm);
+  dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
+#define CSTP_K1S_STR(MT_) \
+  hipLaunchKernelGGL((igemm_k1s<MT_, false, 1, 2, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), xp, bias, \
+                     y, ntx, ntm, inv_a, cells)
+  if (tl.mt == 4) CSTP_K1S_STR(4); else if (tl.mt == 5) CSTP_K1S_STR(5); else CSTP_K1S_STR(6);
+#undef CSTP_K1S_STR
+}
+
 // pack the weights for the patch kernel, make sure the gathered tensor's absmax cell is filled, launch it
 // (forward: src = x, Cs = c, M = k;  data gradient: src = dy, Cs = k, M = c -- a 3x3 stride-1 convolution with mirrored taps)
 static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
@@ -1133,6 +1172,11 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
   }
   if (p.f_t.sp == 2 && bias == nullptr) {
     run_k1p(p.f_t, s, d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
+  if (p.f_t.sp == 1 && p.f_straddle && !(in_affine != nullptr && in_affine->scale_shift != nullptr)) {
+    run_k1s_stem(p.f_t, s, d, p, w, x, bias, y, ws, plan_main_bytes(d, p));
     CSTP_LAUNCH_CHECK();
     return 0;
   }
@@ -1323,7 +1367,7 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   const Tile& t = mode == 0 ? p.f_t : p.d_t;
   out4[0] = tile_bm(t);
   out4[1] = tile_bn(t);
-  out4[2] = (t.sp && !(mode == 0 && p.f_straddle)) ? split_planes() : 0;       // (the patch kernel: f16 pair, 224 positions)
+  out4[2] = t.sp ? split_planes() : 0;       // (the patch kernel and the stems' straddle mode: f16 pair only -- make_plan)
   out4[3] = t.tpb == 2 ? 2 : 1;
   return 0;
 }
@@ -1479,6 +1523,10 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
         if (mt >= 8) cand[ncand++] = Tile{mt, 2, 0, 1, 1};      // 256-column tile
       }
     }
+  }
+  if (allow_split && straddle && split_planes() == 2) {      // the stems: split tiles in straddle mode, 64 / 80 / 96 rows
+    for (int mt = 4; mt <= 6; ++mt)
+      if (cdiv(M, 16 * mt) * 16 * mt - M <= 16 + M / 8 && ncand < 40) cand[ncand++] = Tile{mt, 1, 0, 1, 1};
   }
   if (allow_split && patch_geom_ok(d)) {       // the LDS-resident-patch kernel: row blocks of 64 / 128 / 144
     static const int pmt[] = {4, 8, 9};

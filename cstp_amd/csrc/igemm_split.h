@@ -222,7 +222,40 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
 // NP = planes per operand: 3 = bf16 triple (six products), 2 = f16 pair (three products; inv_a = per-row inverse scales of the
 // packed weights, bcell = largest magnitude of the gathered tensor; 128-byte LDS rows, so the 128-column tiles fit twice
 // into a CU's LDS).
-template <int MT, bool DGRAD, int NH, int NP>
+// STR ("straddle", forward only): layers with fewer than 8 input channels (the 3-channel stems).  The reduction index runs
+// k = tap * Cs + c with NO channel padding, so a 16-k group straddles filter taps; the source is a ZERO-PADDED copy of the
+// input (pad_input_kernel: no halo checks at all), every k has its own constant offset from the position's base -- a table in
+// LDS, built once per block -- and the gather adds it to the per-thread offset instead of using the scalar channel stride.
+__global__ void __launch_bounds__(256)
+pad_input_kernel(const float* __restrict__ x, float* __restrict__ xp, unsigned* __restrict__ cell, int planes, int D, int H,
+                 int W, int pt, int ph, int pw) {
+  // xp[plane][D + 2pt][H + 2ph][W + 2pw] = x[plane][D][H][W] inside, 0 around; *cell = max |x| (fp32 bits) as a by-product
+  const int Dq = D + 2 * pt, Hq = H + 2 * ph, Wq = W + 2 * pw;
+  const size_t total = (size_t)planes * Dq * Hq * Wq;
+  unsigned mx = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Wq);
+    size_t r = i / Wq;
+    const int h = (int)(r % Hq);
+    r /= Hq;
+    const int d = (int)(r % Dq);
+    const size_t pl = r / Dq;
+    const int id = d - pt, ih = h - ph, iw = w - pw;
+    float v = 0.f;
+    if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+      v = x[((pl * D + id) * H + ih) * W + iw];
+    xp[i] = v;
+    const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+    mx = mx > a ? mx : a;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+  if ((threadIdx.x & 63) == 0 && mx != 0) atomicMax(cell, mx);
+}
+
+constexpr int STR_KMAX = 1056;                       // table entries: 7x7x7 taps x 3 channels = 1029, padded to 16
+
+template <int MT, bool DGRAD, int NH, int NP, bool STR = false>
 __global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 4 : 1)      // the f16-pair 128-column tiles: two blocks per CU (<= 128 VGPRs)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
@@ -241,7 +274,9 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
   auto chunk_at = [](int row, int plane, int c) __attribute__((always_inline)) -> int {
     return NP == 2 ? ((plane * 4 + c) ^ (row & 7)) : (plane * 4 + (c ^ spl_swz(row)));
   };
+  static_assert(!STR || (!DGRAD && NH == 1), "the straddle mode serves the forward 128-column tiles");
   __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
+  __shared__ __attribute__((aligned(16))) unsigned ktab[STR ? STR_KMAX : 4];   // STR: byte offset of reduction index k
   __shared__ __attribute__((aligned(16))) float inva_s[NP == 2 ? BM : 4];   // NP == 2: inverse row scales of this row tile
 
   const int t = threadIdx.x, lane = t & 63;
@@ -289,7 +324,17 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     __syncthreads();
     nvt = __builtin_amdgcn_readfirstlane(vtap[27]);
   }
-  const int ngroups = nvt * gpt;
+  if (STR) {
+    const int HWq = g.Hs * g.Ws, kreal = ntaps * g.Cs;
+    for (int k = t; k < g.Ktot; k += 512) {
+      const int kk = k < kreal ? k : kreal - 1;       // the padding k's carry zero weights: any in-range address will do
+      const int tp = kk / g.Cs, c = kk - tp * g.Cs;
+      const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+      ktab[k] = (unsigned)((c * g.Ds + dt) * HWq + dh * g.Ws + dw) * 4u;
+    }
+    __syncthreads();
+  }
+  const int ngroups = STR ? (g.Ktot >> 4) : nvt * gpt;
   const int ntiles = (ngroups + 1) >> 1;
 
   if (wave >= 4) {
@@ -348,7 +393,8 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 
     // my group sequence: e = g2, g2 + 2, ... ; (ord, cg) = (tap ordinal, 16-channel block inside the tap), kept
     // incrementally (no division in the loop)
-    int ord = g2 / gpt, cg = g2 - ord * gpt;
+    const int gpt_ = STR ? 1 : gpt;                   // (STR: gpt is 0 -- no per-tap channel groups)
+    int ord = g2 / gpt_, cg = g2 - ord * gpt_;
     int e = g2;
     unsigned vb0[NH];                                 // per-thread byte offset of channel 0 at the current tap (or OOB); the
                                                       // channel stride rides in the scalar offset of each load
@@ -369,7 +415,15 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       }
       return tp;
     };
-    int tap = set_tap();
+    int tap = 0;
+    if (STR) {
+      // zero-padded source: the window of output position (d, h, w) starts at (d st, h sh, w sw), always inside
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        vb0[h] = nvalid[h] ? src_b4[h] + (unsigned)((npd[h] * g.st) * HWs + (nph[h] * g.sh) * g.Ws + npw[h] * g.sw) * 4u : OOB;
+    } else {
+      tap = set_tap();
+    }
 
     u32x4 ra0[A_IT], ra1[A_IT];
     float rb0[NH][16], rb1[NH][16];
@@ -377,10 +431,25 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // issue the loads of my current group into the given register set, then advance to my next group
     auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
       const bool have = e < ngroups;                  // uniform; a missing group loads zeros (OOB offsets)
-      const unsigned sa = (unsigned)(((size_t)(tap * gpt + cg) * g.Mp + m0) * (32 * NP));
+      const unsigned sa = (unsigned)(((size_t)(STR ? e : tap * gpt + cg) * g.Mp + m0) * (32 * NP));
       const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
 #pragma unroll
       for (int j = 0; j < A_IT; ++j) buf_load_x4(ra[j], j == A_IT - 1 ? vlast : vfull, rs_w, sa + 2048u * j);
+      if constexpr (STR) {
+        // every k of the group has its own offset: four 16-byte reads of the table (same address in all lanes: broadcast)
+        const uint4* kt4 = reinterpret_cast<const uint4*>(ktab + 16 * (have ? e : 0));
+        const unsigned vo = have ? vb0[0] : OOB;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const uint4 o = kt4[j4];
+          buf_load_x1(rb[0][4 * j4 + 0], vo + o.x, rs_src, 0);
+          buf_load_x1(rb[0][4 * j4 + 1], vo + o.y, rs_src, 0);
+          buf_load_x1(rb[0][4 * j4 + 2], vo + o.z, rs_src, 0);
+          buf_load_x1(rb[0][4 * j4 + 3], vo + o.w, rs_src, 0);
+        }
+        e += 2;
+        return;
+      }
       const unsigned sb = have ? (unsigned)(cg << 4) * ch4 : 0u;    // scalar part: first channel of the block
 #pragma unroll
       for (int h = 0; h < NH; ++h) {

@@ -344,3 +344,32 @@ def test_deterministic_weight_gradient_is_bit_reproducible(tile):
     finally:
         ops.set_deterministic(False)
     assert lib.cstp_get_deterministic() == 0
+
+
+# ---- the 3-channel stems on the split kernel's straddle mode (zero-padded input copy, per-k offset table) ---------------------
+STEMS = {
+    "r21d": ((2, 3, 4, 28, 28), 83, (1, 7, 7), (1, 2, 2), (0, 3, 3)),        # R(2+1)D stem: 147-long reduction, 83 rows -> 96
+    "r21d_odd": ((3, 3, 3, 23, 19), 83, (1, 7, 7), (1, 2, 2), (0, 3, 3)),    # odd extents, ragged last tile
+    "r3d": ((1, 3, 6, 20, 20), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),         # 3D-ResNet stem: 1029-long reduction, padding in D too
+}
+
+
+@pytest.mark.parametrize("mt", [4, 5, 6])
+@pytest.mark.parametrize("name", list(STEMS))
+def test_stem_on_the_split_kernel(name, mt):
+    from cstp_amd import ops
+    import ctypes
+    from cstp_amd import _lib
+    GEOMS["_stem"] = STEMS[name]
+    xs, k, ks, st, pd = STEMS[name]
+    ops.set_split_terms(2)
+    try:
+        _run("_stem", {0: (1, mt, 0, 0), 1: (0, 2, 1, 1), 2: (0, 3, 4, 0)})
+        out = (ctypes.c_int32 * 4)()
+        desc = ops._desc(xs, (k, xs[1]) + ks, st, pd)
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(desc), 0, out), "query")
+        assert list(out)[:3] == [16 * mt, 128, 2]
+        _run("_stem", {0: (1, mt, 0, 0), 1: (0, 2, 1, 1), 2: (0, 3, 4, 0)}, scale_x=3e15, scale_w=1e-9)
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_stem"]
