@@ -10,21 +10,24 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cstp_amd import ops  # noqa: E402
 
-LAYERS = {"S1": ((32, 64, 16, 56, 56), 144), "S3": ((32, 128, 8, 28, 28), 288), "S5": ((32, 256, 4, 14, 14), 576)}
+LAYERS = {"S1": ((32, 64, 16, 56, 56), 144), "S3": ((32, 128, 8, 28, 28), 288), "S5": ((32, 256, 4, 14, 14), 576),
+          "T1": ((32, 144, 16, 56, 56), 64), "T3": ((32, 288, 8, 28, 28), 128), "T5": ((32, 576, 4, 14, 14), 256)}
 name = sys.argv[1] if len(sys.argv) > 1 else "S1"
 mode = 1 if (len(sys.argv) > 2 and sys.argv[2] == "dgrad") else 0
 tile = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else ((2, 9, 0, 0) if mode == 0 else (2, 4, 0, 0))
 xs, k = LAYERS[name]
 lib = ops._lib.load()
 x = torch.randn(xs, device="cuda")
-w = torch.randn(k, xs[1], 1, 3, 3, device="cuda") * 0.05
-desc = ops._desc(xs, tuple(w.shape), (1, 1, 1), (0, 1, 1))
+temporal = name.startswith("T")
+ks, pad = ((3, 1, 1), (1, 0, 0)) if temporal else ((1, 3, 3), (0, 1, 1))
+w = torch.randn((k, xs[1]) + ks, device="cuda") * 0.05
+desc = ops._desc(xs, tuple(w.shape), (1, 1, 1), pad)
 y = torch.empty((xs[0], k) + xs[2:], device="cuda")
 dy = torch.randn_like(y)
 dx = torch.empty_like(x)
 wsb = torch.empty(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-ops.set_conv_tile(xs, tuple(w.shape), (1, 1, 1), (0, 1, 1), mode, tile)
+ops.set_conv_tile(xs, tuple(w.shape), (1, 1, 1), pad, mode, tile)
 cell = (x if mode == 0 else dy).abs().max().view(torch.int32).clone()
 if mode == 0:
     fn = lambda: ops.check(lib.cstp_conv3d_forward_am(st, ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(),
@@ -44,7 +47,7 @@ for _ in range(5):
     b.record()
     b.synchronize()
     ts.append(a.elapsed_time(b) / 10)
-gf = 2.0 * xs[0] * xs[2] * xs[3] * xs[4] * k * xs[1] * 9 / 1e9
+gf = 2.0 * xs[0] * xs[2] * xs[3] * xs[4] * k * xs[1] * (3 if temporal else 9) / 1e9
 print("%s %s tile %s lib %s: min %.3f ms med %.3f ms  %.1f TF/s (incl. %s pack)" % (
     name, "dgrad" if mode else "fwd", tile, os.path.basename(os.environ.get("CSTP_LIB_PATH", "default")), min(ts),
     sorted(ts)[2], gf / min(ts), "weight"))

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 out=$R/gpurun_out/pmc_$mode
 rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $set | tr ' ' '+')
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag -- python3 $R/tools/one_conv.py $mode 32 > $out/$tag.log 2>&1
   f=$(ls $out/$tag/*/*counter_collection.csv 2>/dev/null | head -1)

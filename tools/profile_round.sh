@@ -1,21 +1,29 @@
 #!/bin/bash
-# end-of-round evidence: kernel traces of the bench (default = overlapped streams; serial for per-kernel costs), the PMC passes
-# on the S1 forward / weight-gradient kernels, and the default bench line.  Run from the repo root on the GPU box.
+# end-of-round evidence, run from the repo root on the GPU box:  bash tools/profile_round.sh
+#   1. a default bench run that (re)writes the persisted tile table cstp_amd/tuned/ (copied out for committing);
+#   2. kernel traces of the bench: default (overlapped streams) and serial (per-kernel costs);
+#   3. PMC passes (one rocprofv3 run per counter set) on the S1 forward / data-gradient / weight-gradient kernels;
+#   4. the default bench line(s).
 set -e
 R=$PWD
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
+python3 bench.py --no-cpu-baseline > $O/bench_tune_run.json.log 2>$O/bench_tune_run.err
+python3 bench.py --depth 34 --no-cpu-baseline --no-extras > $O/bench_r34_t16.json.log 2>>$O/bench_tune_run.err
+python3 bench.py --depth 34 --batch 8 --frames 32 --no-cpu-baseline --no-extras > $O/bench_r34_t32_cfg4.json.log 2>>$O/bench_tune_run.err
+cp cstp_amd/tuned/*.json $O/
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/trace_overlap.log 2>&1
-CSTP_OVERLAP_WGRAD=0 CSTP_OVERLAP_TARGET=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/trace_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/trace_overlap.log 2>&1
+CSTP_OVERLAP_WGRAD=0 CSTP_OVERLAP_TARGET=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/trace_serial.log 2>&1
 cd $R
-python3 profiles/summarize.py --trace $O/trace_overlap/run_kernel_trace.csv 3 > $O/bench_last3steps_f16_overlap.txt
-python3 profiles/summarize.py --trace $O/trace_serial/run_kernel_trace.csv 3 > $O/bench_last3steps_f16_serial.txt
-cp $O/trace_overlap/run_kernel_stats.csv $O/bench_f16_overlap_kernel_stats.csv
-cp $O/trace_serial/run_kernel_stats.csv $O/bench_f16_serial_kernel_stats.csv
+python3 profiles/summarize.py --trace $O/trace_overlap/run_kernel_trace.csv 3 > $O/bench_last3steps_overlap.txt
+python3 profiles/summarize.py --trace $O/trace_serial/run_kernel_trace.csv 3 > $O/bench_last3steps_serial.txt
+cp $O/trace_overlap/run_kernel_stats.csv $O/bench_overlap_kernel_stats.csv
+cp $O/trace_serial/run_kernel_stats.csv $O/bench_serial_kernel_stats.csv
 rm -rf $O/trace_overlap $O/trace_serial
 bash tools/pmc_s1.sh fwd > $O/pmc_fwd.txt 2>&1
+bash tools/pmc_s1.sh dgrad > $O/pmc_dgrad.txt 2>&1
 bash tools/pmc_s1.sh wgrad > $O/pmc_wgrad.txt 2>&1
 python3 bench.py > $O/bench_default_run.json.log 2>$O/bench_default_run.err
 tail -1 $O/bench_default_run.json.log | cut -c1-300
-head -12 $O/bench_last3steps_f16_serial.txt
+head -14 $O/bench_last3steps_serial.txt
