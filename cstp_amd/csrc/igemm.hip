@@ -1389,6 +1389,14 @@ extern "C" int cstp_conv3d_get_tile(const cstp_conv_desc* desc, int32_t mode, in
   return 0;
 }
 
+#if KP_DIAG & 16
+extern "C" int cstp_debug_stamps(unsigned long long* out8) {      // diagnostic builds only: read and reset the k1p stamps
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cstp::kp_stamp), sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(cstp::kp_stamp), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int cstp_gemm_set_split_terms(int32_t terms) {
   CSTP_REQUIRE(terms >= 0 && terms <= 3, "split terms: 2 (f16 pair), 3 (bf16 triple), 1 (native f32 MFMA only) or 0 (environment default)");
   g_split_terms.store(terms, std::memory_order_relaxed);

@@ -32,6 +32,14 @@
 
 namespace cstp {
 
+#if KP_DIAG & 16
+// in-kernel stamps of consumer wave 0 of block 0 (diagnostic builds only): [0] cycles in K loops, [1] of them waiting at the
+// barrier (incl. the lgkmcnt drain in front of it), [2] from the top of a K-tile until its weight fragments have landed,
+// [3] epilogue cycles, [4] K-tiles, [5] items, [6] s_memrealtime ticks (100 MHz) over the K loops
+__device__ unsigned long long kp_stamp[8];
+#define KP_T() __builtin_amdgcn_s_memtime()
+#endif
+
 constexpr int KP_NPOS = 224;        // output positions per block
 constexpr int KP_NTW = 7;           // 16-column MFMA tiles per consumer wave (two wave columns)
 constexpr int KP_ROWS = 400;        // LDS rows (image positions incl. halo) per patch buffer: the host checks the geometry fits
@@ -182,7 +190,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // Wave 6 gathers channels 0..15 of each 32-channel block, wave 7 channels 16..31; lane l owns LDS rows l + 64 r.  They share
     // their SIMDs with the second row-wave's consumers (waves 2, 3), which own one row tile fewer when MT is odd.  Seven rounds
     // of (16 dword gathers -> split -> four 16-byte LDS stores) stage the NEXT channel block's patch while the current one is
-    // multiplied: round r loads at tap r and stores at tap r + 2.  No load is conditional -- a round with nothing to stage
+    // multiplied (schedule below).  No load is conditional -- a round with nothing to stage
     // gathers through out-of-range offsets (zeros, no memory traffic) -- so the compiler's s_waitcnt accounting keeps two
     // rounds in flight with counted waits (igemm_split.h explains what a conditional load costs).
     constexpr int NR = (KP_ROWS + 63) / 64;            // 7
@@ -225,6 +233,9 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     const unsigned ch4 = (unsigned)(chs * 4);
     // channels past the tensor's last one (ragged last block) re-read the last channel: their packed weights are zero
     auto b_load = [&](unsigned vo, int cb, float (&v)[16]) __attribute__((always_inline)) {
+#if KP_DIAG & 64
+      { _Pragma("unroll") for (int j = 0; j < 16; ++j) v[j] = __builtin_bit_cast(float, vo + j); return; }   // no loads: split + store only
+#endif
       const int c0 = cb * 32 + half * 16;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -234,6 +245,9 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     };
     auto b_store = [&](int buf, int r, const float (&v)[16]) __attribute__((always_inline)) {
       const int l = lane + 64 * r;
+#if KP_DIAG & 32
+      { _Pragma("unroll") for (int j = 0; j < 16; ++j) asm volatile("" :: "v"(v[j])); return; }      // loads only: no split, no store
+#endif
       uint4 ph[2], pl[2];
       unsigned hh, ll;
 #define CSTP_SPLITH(J, DST, F) split2h(v[J], v[(J) + 1], sb, hh, ll); ph[DST].F = hh; pl[DST].F = ll;
@@ -265,7 +279,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    float rb[2][16];
+    float rb[NR][16];                                 // all rounds of a channel block in flight
     int pb = 0;                                       // patch buffer of the channel block being consumed
     for (int it = 0; it < nitems; ++it) {
       const bool next_item = it + 1 < nitems;
@@ -277,12 +291,23 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
           patch_offsets(tile, voff_nxt);
         }
         const int ncb_ = last_cb ? 0 : cb + 1;
+        // rounds 2 t, 2 t + 1 are LOADED at tap t (t = 0..3) and STORED four taps later: a gather has ~4 K-tiles (4-5 us) to
+        // come back from HBM.  (Stored two taps after the load, the staging waves regularly reached the barrier late -- in-kernel
+        // stamps: 277 instead of 58 cycles of barrier wait per K-tile, 0.81 instead of 0.66 ms for the S1 layer.)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          if (tap >= 2 && tap - 2 < NR) b_store(pb ^ 1, tap - 2, rb[tap & 1]);
-          if (tap < NR) {
-            const unsigned vo = stage ? (last_cb ? voff_nxt[tap] : voff_cur[tap]) : OOB;
-            b_load(vo, ncb_, rb[tap & 1]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rs = 2 * (tap - 4) + e;            // the round stored at this tap
+            if (tap >= 4 && rs < NR) b_store(pb ^ 1, rs, rb[rs]);
+          }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rl = 2 * tap + e;                   // the round loaded at this tap
+            if (rl < NR) {
+              const unsigned vo = stage ? (last_cb ? voff_nxt[rl] : voff_cur[rl]) : OOB;
+              b_load(vo, ncb_, rb[rl]);
+            }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
@@ -304,7 +329,6 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   float invb, sc_unused;
   f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
   const int q = lane >> 4;
-  const bool odd = (q & 1) != 0;
 
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
   __builtin_amdgcn_s_setprio(2);                       // the matrix stream outranks the staging waves it shares SIMDs with
@@ -344,29 +368,45 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // in LDS long before they are needed, also the next K-tile's; only the weight fragments wait for the barrier, and of
     // those only the first row tile's two reads are exposed.  Loop order: column tile outer, row tile inner (independent
     // accumulators back to back).
+    // The B fragment reads are INLINE ASM with hand-placed waits: left to the compiler (VGPR budget exhausted by 140
+    // accumulators) it hoisted half of each pair to the top of the K-tile and issued the other half right in front of its first
+    // use -- seven exposed LDS latencies per K-tile, 22 instead of 16 cycles per MFMA (in-kernel stamps).  As asm the pair for
+    // column tile j + 1 is issued in front of column tile j's fifteen products and awaited behind them.
     f16x8 bh[2], bl[2];
-    auto load_b = [&](int buf, int j, const uint4* Bp, int ts) __attribute__((always_inline)) {
+    const unsigned patch_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)patch);
+    auto load_b = [&](int buf, int j, unsigned pbuf_bytes, int ts) __attribute__((always_inline)) {
       const int row = base[j] + ts;
       const int qq = fk ^ (row & 7);
-      bh[buf] = __builtin_bit_cast(f16x8, Bp[row * 8 + qq]);
-      bl[buf] = __builtin_bit_cast(f16x8, Bp[row * 8 + (qq ^ 4)]);
+      const unsigned addr = pbuf_bytes + (unsigned)(row * 8 + qq) * 16u;      // the lo plane sits 4 chunks (64 bytes) away: ^ 64
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(bh[buf]), "=&v"(bl[buf]) : "v"(addr), "v"(addr ^ 64u));
+      __builtin_amdgcn_sched_barrier(0);             // the products that follow stay BEHIND the issue (rule: asm orders nothing)
     };
-    load_b(0, 0, patch + pb * P_U4, 0);               // K-tile 0 of this item: already staged
+    load_b(0, 0, patch_lds + pb * (P_U4 * 16), 0);     // K-tile 0 of this item: already staged
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     const int arow0 = (mt0 * 16 + fr) * 8;
 
     // one K-tile per iteration, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
     // 9 x 7 x 2 fragment addresses out of the loop (126 VGPRs) and spills the accumulators
     int tap = 0, slot3 = 0, dh_pitch = 0, dw = 0;
+#if KP_DIAG & 16
+    const bool stamp = blockIdx.x == 0 && wave == 0;
+    unsigned long long s_loop = 0, s_bar = 0, s_a = 0;
+    const unsigned long long t_loop0 = KP_T(), r_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
     for (int kt = 0; kt < nkt; ++kt) {
+#if KP_DIAG & 16
+      const unsigned long long t_top = KP_T();
+#endif
       const uint4* Ab = ring + slot3 * A_U4;
-      const uint4* Bp = patch + pb * P_U4;
+      const unsigned Bp = patch_lds + pb * (P_U4 * 16);
       const int ts = dh_pitch + dw;
       // the NEXT K-tile's tap shift / patch buffer
       int ntap = tap + 1, ndw = dw + 1, ndh = dh_pitch, npb = pb;
       if (ndw == 3) { ndw = 0; ndh += PITCH; }
       if (ntap == 9) { ntap = 0; ndh = 0; npb ^= 1; }
-      const uint4* Bn = patch + npb * P_U4;
+      const unsigned Bn = patch_lds + npb * (P_U4 * 16);
       const int nts = ndh + ndw;
 
       f16x8 ah[NI], al[NI];
@@ -375,6 +415,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         ah[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa0]);
         al[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa1]);
       }
+#if KP_DIAG & 16
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      s_a += KP_T() - t_top;
+#endif
 #pragma unroll
       for (int j = 0; j < KP_NTW; ++j) {
         if (j + 1 < KP_NTW) load_b((j + 1) & 1, j + 1, Bp, ts);
@@ -391,20 +435,37 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], blj, acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bhj, acc[i][j], 0, 0, 0);
+        // column tile j + 1's fragments (issued in front of these products) have landed; nothing moves across these points
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
       // (KP_NTW is odd: the next K-tile's first fragments landed in buffer KP_NTW & 1 -- move them to buffer 0)
       bh[0] = bh[KP_NTW & 1];
       bl[0] = bl[KP_NTW & 1];
       slot3 = slot3 == 2 ? 0 : slot3 + 1;
       tap = ntap; dw = ndw; dh_pitch = ndh; pb = npb;
+#if KP_DIAG & 16
+      const unsigned long long t_b0 = KP_T();
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#if KP_DIAG & 16
+      s_bar += KP_T() - t_b0;
+#endif
     }
+#if KP_DIAG & 16
+    const unsigned long long t_loop1 = KP_T(), r_loop1 = __builtin_amdgcn_s_memrealtime();
+    s_loop = t_loop1 - t_loop0;
+#endif
     // (pb has moved on to the buffer that holds the next item's first channel block)
 
-    // ---- epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Column tiles are stored in pairs: lane groups q
-    // and q ^ 1 swap one register so that 32 consecutive lanes hold 32 consecutive positions of ONE row (whole 128-byte
-    // lines); the seventh tile goes out in 64-byte segments.
+    // ---- epilogue.  C layout: col = lane & 15, row = (lane >> 4) * 4 + reg -- a lane holds FOUR ROWS of one position, and
+    // one 4-byte store per value makes 140 store instructions per lane: measured (in-kernel stamps) 18 k cycles per item, a
+    // quarter of the kernel, store-ISSUE bound.  So every 4 x 4 block (4 lanes of a quad x 4 registers) is transposed inside
+    // its quad with DPP moves: lane t then holds row 4 q + t and FOUR CONSECUTIVE POSITIONS 4 (fr >> 2) .. + 3 of it, and the
+    // tile goes out in 16-byte stores -- a quarter of the instructions, 64-byte runs per row.  (Needs the frame size to be a
+    // multiple of 4 positions, else the four positions may straddle frames: such layers -- 7 x 7 -- keep the scalar stores.)
     auto out_base = [&](int pos, bool& ok) __attribute__((always_inline)) -> size_t {
       ok = pos < P;
       const int pp = ok ? pos : 0;
@@ -412,47 +473,66 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       const int nb = f / g.D, d = f - nb * g.D;
       return ((size_t)nb * g.M * g.D + d) * HW + sp;
     };
+    const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;     // uniform
+    if (vec_ok) {
+      const int tq = fr & 3, cq = fr >> 2;              // my row inside the 4-row group / my group of four positions
+      const bool lo1 = (tq & 1) == 0, lo2 = (tq & 2) == 0;
+      auto xchg = [](float v, int ctrl) __attribute__((always_inline)) -> float {
+        const int vi = __builtin_bit_cast(int, v);
+        return __builtin_bit_cast(float, ctrl == 1 ? __builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xF, 0xF, false)     // lanes t <-> t ^ 1
+                                                   : __builtin_amdgcn_update_dpp(vi, vi, 0x4E, 0xF, 0xF, false));  // lanes t <-> t ^ 2
+      };
 #pragma unroll
-    for (int pr = 0; pr < KP_NTW / 2; ++pr) {
-      bool nok;
-      const size_t obase = out_base(pos0 + (wn * KP_NTW + 2 * pr) * 16 + (lane & 31), nok);
+      for (int j = 0; j < KP_NTW; ++j) {
+        bool nok;
+        const size_t obase = out_base(pos0 + (wn * KP_NTW + j) * 16 + 4 * cq, nok);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        {
-          const int mrow = (mt0 + i) * 16 + (q & ~1) * 4;
-          const f32x4 ia0 = *reinterpret_cast<const f32x4*>(&inva[mrow]) * invb;
-          const f32x4 ia1 = *reinterpret_cast<const f32x4*>(&inva[mrow + 4]) * invb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v0 = acc[i][2 * pr][r], v1 = acc[i][2 * pr + 1][r];
-            const float recv = __shfl_xor(odd ? v0 : v1, 16, 64);
-            const int m_even = mblk * BM + mrow + r, m_odd = m_even + 4;
-            const float ve = (odd ? recv : v0) * ia0[r];
-            const float vo = (odd ? v1 : recv) * ia1[r];
-            if ((KP_DIAG & 8) && ve != 12345.f) continue;
-            if (nok && m_even < g.M) CSTP_STORE(out + obase + (size_t)m_even * chs, ve);
-            if (nok && m_odd < g.M) CSTP_STORE(out + obase + (size_t)m_odd * chs, vo);
+        for (int i = 0; i < NI; ++i) {
+          float r0 = acc[i][j][0], r1 = acc[i][j][1], r2 = acc[i][j][2], r3 = acc[i][j][3];
+          // 2 x 2 blocks: even lanes hand register 1 (3) to their neighbour and take its register 0 (2), and vice versa
+          float y = xchg(lo1 ? r1 : r0, 1);
+          if (lo1) r1 = y; else r0 = y;
+          y = xchg(lo1 ? r3 : r2, 1);
+          if (lo1) r3 = y; else r2 = y;
+          // ... then the 2 x 2 blocks themselves across lanes t <-> t ^ 2: registers (0, 2) and (1, 3)
+          y = xchg(lo2 ? r2 : r0, 2);
+          if (lo2) r2 = y; else r0 = y;
+          y = xchg(lo2 ? r3 : r1, 2);
+          if (lo2) r3 = y; else r1 = y;
+          const int mrow = (mt0 + i) * 16 + q * 4 + tq;
+          const float sc = inva[mrow] * invb;
+          const int m = mblk * BM + mrow;
+          if ((KP_DIAG & 8) && r0 != 12345.f) continue;
+          if (nok && m < g.M) {
+            const f32x4 v = {r0 * sc, r1 * sc, r2 * sc, r3 * sc};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + obase + (size_t)m * chs));
           }
         }
       }
-    }
-    {
-      bool nok;
-      const size_t obase = out_base(pos0 + (wn * KP_NTW + KP_NTW - 1) * 16 + fr, nok);
+    } else {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        {
+      for (int j = 0; j < KP_NTW; ++j) {
+        bool nok;
+        const size_t obase = out_base(pos0 + (wn * KP_NTW + j) * 16 + fr, nok);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
           const int mrow = (mt0 + i) * 16 + q * 4;
           const f32x4 ia = *reinterpret_cast<const f32x4*>(&inva[mrow]) * invb;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mblk * BM + mrow + r;
-            if ((KP_DIAG & 8) && acc[i][KP_NTW - 1][r] != 12345.f) continue;
-            if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][KP_NTW - 1][r] * ia[r]);
+            if ((KP_DIAG & 8) && acc[i][j][r] != 12345.f) continue;
+            if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][j][r] * ia[r]);
           }
         }
       }
     }
+#if KP_DIAG & 16
+    if (stamp && lane == 0) {
+      kp_stamp[0] += s_loop; kp_stamp[1] += s_bar; kp_stamp[2] += s_a; kp_stamp[3] += KP_T() - t_loop1;
+      kp_stamp[4] += (unsigned long long)nkt; kp_stamp[5] += 1; kp_stamp[6] += r_loop1 - r_loop0;
+    }
+#endif
   }
   };
   if constexpr (MT - MTW == MTW) {

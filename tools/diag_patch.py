@@ -51,3 +51,16 @@ gf = 2.0 * xs[0] * xs[2] * xs[3] * xs[4] * k * xs[1] * (3 if temporal else 9) / 
 print("%s %s tile %s lib %s: min %.3f ms med %.3f ms  %.1f TF/s (incl. %s pack)" % (
     name, "dgrad" if mode else "fwd", tile, os.path.basename(os.environ.get("CSTP_LIB_PATH", "default")), min(ts),
     sorted(ts)[2], gf / min(ts), "weight"))
+
+if hasattr(lib, "cstp_debug_stamps"):          # a -DKP_DIAG=16 build: in-kernel stamps of consumer wave 0 of block 0
+    import ctypes as C
+    buf = (C.c_ulonglong * 8)()
+    lib.cstp_debug_stamps(buf)                 # reset
+    fn()
+    torch.cuda.synchronize()
+    lib.cstp_debug_stamps(buf)
+    loop, bar, a, epi, kts, items, real = [int(v) for v in buf][:7]
+    print("stamps (one launch, wave 0 of block 0): %d items, %d K-tiles; per K-tile %.0f cycles, of which barrier wait %.0f, "
+          "A-fragment wait %.0f; epilogue %.0f cycles per item; clock %.2f GHz"
+          % (items, kts, loop / max(kts, 1), bar / max(kts, 1), a / max(kts, 1), epi / max(items, 1),
+             loop / max(real, 1) * 0.1))
