@@ -1391,7 +1391,7 @@ extern "C" int cstp_conv3d_get_tile(const cstp_conv_desc* desc, int32_t mode, in
 
 #if KP_DIAG & 16
 extern "C" int cstp_debug_stamps(unsigned long long* out8) {      // diagnostic builds only: read and reset the k1p stamps
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long zero[8] = {};
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cstp::kp_stamp), sizeof(zero)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(cstp::kp_stamp), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
 }

@@ -323,7 +323,11 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   // =================================================== consumers ===================================================
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fk = lane >> 4;
-  const int mt0 = wm * MTW;                           // my first row tile; I own MTW (wm = 0) or MT - MTW (wm = 1) of them
+  // Row tiles: each row-wave owns MT / 2 whole row tiles (all 7 of its column tiles).  When MT is odd the LAST row tile is
+  // shared by all four consumers, each taking it on a part of its own column tiles -- the first row-wave on column tiles
+  // 0..3, the second on 4..6: 32 / 31 products per tap and wave instead of 35 / 28 when one row-wave owned five row tiles.
+  constexpr int NIF = MT / 2;
+  const int mt0 = wm * NIF;
   // my A fragment chunks (rows fr + 16 i: (row & 7) == (fr & 7))
   const int qa0 = fk ^ (fr & 7), qa1 = (4 + fk) ^ (fr & 7);
   float invb, sc_unused;
@@ -333,48 +337,65 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
   __builtin_amdgcn_s_setprio(2);                       // the matrix stream outranks the staging waves it shares SIMDs with
 
-  // NI = row tiles of this wave: MTW for the first row-wave, MT - MTW for the second (one fewer when MT is odd) -- two
-  // instantiations of the body instead of a branch around every fifth product
-  auto body = [&](auto ni_tag) __attribute__((always_inline)) {
-  constexpr int NI = decltype(ni_tag)::value;
+  // two instantiations of the body (the shared row tile's column range is a compile-time constant) instead of branches
+  auto body = [&](auto xj0_tag, auto xjn_tag) __attribute__((always_inline)) {
+  constexpr int NI = NIF;
+  constexpr int XJ0 = decltype(xj0_tag)::value, XJN = decltype(xjn_tag)::value;      // the shared row tile: my column tiles of it
+  constexpr int XA = XJN > 0 ? 1 : 0;
   int pb = 0;
   for (int it = 0; it < nitems; ++it) {
     int tile, mblk;
     item_of(it, tile, mblk);
     const int pos0 = tile * KP_NPOS;
-    const int v_lo = pos0 / W, f_lo = v_lo / H;
+    // (pos0 is uniform: these three divisions are the item's only ones -- every per-lane position below is reached from
+    // them by stepping; one division pair per column tile and lane, here and in the epilogue, was 28 x ~35 instructions per item)
+    const int v_lo = pos0 / W, w_lo = pos0 - v_lo * W;
+    const int f_lo = v_lo / H, h_lo = v_lo - f_lo * H;
     float* const inva = inva_s + (it & 1) * BM;
     if (t < BM) inva[t] = inv_a[mblk * BM + t];       // read back in this item's epilogue, >= 9 barriers later
 
     f32x4 acc[NI][KP_NTW];
+    f32x4 accx[XJN > 0 ? XJN : 1];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < KP_NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (XJN > 0 ? XJN : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accx[j][r] = 0.f;
 
     // LDS row of my column in each of my 7 column tiles, one line above / one column left of it; a tap adds dh * PITCH + dw
     int base[KP_NTW];
+    {
+      int w = w_lo + wn * (KP_NTW * 16) + fr, h = h_lo, dl = 0;      // column, line of the frame, patch lines below the tile's first
 #pragma unroll
-    for (int j = 0; j < KP_NTW; ++j) {
-      int pos = pos0 + (wn * KP_NTW + j) * 16 + fr;
-      pos = pos < P ? pos : P - 1;                    // ragged last tile: compute something valid, never stored
-      const int v = pos / W, w = pos - v * W;
-      base[j] = ((v - v_lo) + 2 * (v / H - f_lo)) * PITCH + w;
+      for (int j = 0; j < KP_NTW; ++j) {
+        while (w >= W) { w -= W; ++dl; if (++h == H) { h = 0; dl += 2; } }
+        // (ragged last tile: past the end read row 0 -- something valid, never stored)
+        base[j] = pos0 + (wn * KP_NTW + j) * 16 + fr < P ? dl * PITCH + w : 0;
+        w += 16;
+      }
     }
 
-    // B fragments (my column tile j at one tap) are double buffered in registers and fetched one column tile ahead -- they sit
-    // in LDS long before they are needed, also the next K-tile's; only the weight fragments wait for the barrier, and of
-    // those only the first row tile's two reads are exposed.  Loop order: column tile outer, row tile inner (independent
-    // accumulators back to back).
-    // The B fragment reads are INLINE ASM with hand-placed waits: left to the compiler (VGPR budget exhausted by 140
+    // B fragments (my column tile j at one tap) sit in LDS long before they are needed, also the next K-tile's; they are
+    // fetched TWO column tiles ahead into three register buffers.  (One tile ahead hides the LDS latency behind a group of
+    // 15 products -- MT = 9 -- but not behind the 6 of MT = 4: in-kernel stamps showed 1970 cycles per K-tile for 672 cycles
+    // of products there.)  Only the weight fragments wait for the barrier.  Loop order: column tile outer, row tile inner
+    // (independent accumulators back to back).
+    // The B fragment reads are INLINE ASM with hand-placed COUNTED waits: left to the compiler (VGPR budget exhausted by the
     // accumulators) it hoisted half of each pair to the top of the K-tile and issued the other half right in front of its first
-    // use -- seven exposed LDS latencies per K-tile, 22 instead of 16 cycles per MFMA (in-kernel stamps).  As asm the pair for
-    // column tile j + 1 is issued in front of column tile j's fifteen products and awaited behind them.
-    f16x8 bh[2], bl[2];
+    // use -- seven exposed LDS latencies per K-tile, 22 instead of 16 cycles per MFMA (in-kernel stamps).  LDS operations
+    // complete in order, so `lgkmcnt(4)` behind the issue of tile j + 2 means tile j has landed whatever the compiler's own
+    // (weight fragment) reads in between; the loop holds no scalar memory load (they return out of order and would break
+    // the count: checked in the disassembly, tools/check_k1p_isa.sh).
+    // The tile sequence runs on across K-tiles (7 per K-tile, buffer = sequence number mod 3), so the K-tile loop is
+    // unrolled by three -- nkt is a multiple of 9 -- with the buffer phase a compile-time constant.
+    f16x8 bh[3], bl[3];
     const unsigned patch_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)patch);
-    // The address of a read is computed one group EARLIER still (among the previous group's products), so that between two
+    // The address of a read is computed one group before its issue (among the previous group's products), so that between two
     // groups of products there is only the wait and the two reads: with the six dependent address instructions there the
     // matrix pipe idled ~45 cycles per group (21 instead of 16 cycles per MFMA).
     auto b_addr = [&](int j, unsigned pbuf_bytes, int ts) __attribute__((always_inline)) -> unsigned {
@@ -382,17 +403,17 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       const int qq = fk ^ (row & 7);
       return pbuf_bytes + (unsigned)(row * 8 + qq) * 16u;                      // the lo plane sits 4 chunks (64 bytes) away: ^ 64
     };
-    auto issue_b = [&](int buf, unsigned addr) __attribute__((always_inline)) {
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(bh[buf]), "=&v"(bl[buf]) : "v"(addr), "v"(addr ^ 64u));
+    auto issue_b = [&](f16x8& dh, f16x8& dl, unsigned addr) __attribute__((always_inline)) {
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(dh), "=&v"(dl) : "v"(addr), "v"(addr ^ 64u));
       __builtin_amdgcn_sched_barrier(0);             // the products that follow stay BEHIND the issue (rule: asm orders nothing)
     };
-    issue_b(0, b_addr(0, patch_lds + pb * (P_U4 * 16), 0));     // K-tile 0 of this item: already staged
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    // K-tile 0 of this item is already staged: its column tiles 0 and 1
+    issue_b(bh[0], bl[0], b_addr(0, patch_lds + pb * (P_U4 * 16), 0));
+    issue_b(bh[1], bl[1], b_addr(1, patch_lds + pb * (P_U4 * 16), 0));
     const int arow0 = (mt0 * 16 + fr) * 8;
-    unsigned addr_n = b_addr(KP_NTW > 1 ? 1 : 0, patch_lds + pb * (P_U4 * 16), 0);     // column tile 1 of K-tile 0
+    unsigned addr_n = b_addr(2, patch_lds + pb * (P_U4 * 16), 0);               // column tile 2 of K-tile 0
 
-    // one K-tile per iteration, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
+    // one K-tile per call, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
     // 9 x 7 x 2 fragment addresses out of the loop (126 VGPRs) and spills the accumulators
     int tap = 0, slot3 = 0, dh_pitch = 0, dw = 0;
 #if KP_DIAG & 16
@@ -400,8 +421,8 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     unsigned long long s_loop = 0, s_bar = 0, s_a = 0;
     const unsigned long long t_loop0 = KP_T(), r_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#pragma unroll 1
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto ktile = [&](auto ph_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_tag)::value;        // buffer of this K-tile's column tile 0
 #if KP_DIAG & 16
       const unsigned long long t_top = KP_T();
 #endif
@@ -415,11 +436,15 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       const unsigned Bn = patch_lds + npb * (P_U4 * 16);
       const int nts = ndh + ndw;
 
-      f16x8 ah[NI], al[NI];
+      f16x8 ah[NI + XA], al[NI + XA];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         ah[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa0]);
         al[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa1]);
+      }
+      if constexpr (XA != 0) {                            // the shared last row tile
+        ah[NI] = __builtin_bit_cast(f16x8, Ab[((MT - 1) * 16 + fr) * 8 + qa0]);
+        al[NI] = __builtin_bit_cast(f16x8, Ab[((MT - 1) * 16 + fr) * 8 + qa1]);
       }
 #if KP_DIAG & 16
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -427,111 +452,135 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 #endif
 #pragma unroll
       for (int j = 0; j < KP_NTW; ++j) {
-        // column tile j + 1 (past the last: tile 0 of the next K-tile; past the item's last K-tile a harmless read, reloaded
-        // at the top of the next item) is requested now; tile j + 2's address is computed among tile j's products
-        issue_b((j + 1) & 1, addr_n);
-        if (j + 2 < KP_NTW) addr_n = b_addr(j + 2, Bp, ts);
-        else addr_n = b_addr(j + 2 - KP_NTW, Bn, nts);
-        const f16x8 bhj = bh[j & 1], blj = bl[j & 1];
+        // column tile j + 2 (past the last: tiles 0, 1 of the next K-tile; past the item's last K-tile harmless reads,
+        // issued again at the top of the next item) is requested now; tile j + 3's address is computed among tile j's products
+        issue_b(bh[(PH + j + 2) % 3], bl[(PH + j + 2) % 3], addr_n);
+        if (j + 3 < KP_NTW) addr_n = b_addr(j + 3, Bp, ts);
+        else addr_n = b_addr(j + 3 - KP_NTW, Bn, nts);
+        // tile j (requested two groups ago) has landed once at most the four youngest reads are outstanding
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 bhj = bh[(PH + j) % 3], blj = bl[(PH + j) % 3];
 #if KP_DIAG & 4
         asm volatile("" :: "v"(bhj), "v"(blj));
-        if (j == 0) { _Pragma("unroll") for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(ah[i]), "v"(al[i])); }
+        if (j == 0) { _Pragma("unroll") for (int i = 0; i < NI + XA; ++i) asm volatile("" :: "v"(ah[i]), "v"(al[i])); }
         continue;
 #endif
+        // (j is a constant after unrolling: this test folds)
+        const bool xj = XJN > 0 && j >= XJ0 && j < XJ0 + XJN;
+        const int jx = xj ? j - XJ0 : 0;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bhj, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[NI + XA - 1], accx[jx], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], blj, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blj, ah[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bhj, acc[i][j], 0, 0, 0);
-        // column tile j + 1's fragments (issued in front of these products) have landed; nothing moves across these points
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
+        // nothing moves across this point: the next group's issue stays behind these products
         __builtin_amdgcn_sched_barrier(0);
       }
-      // (KP_NTW is odd: the next K-tile's first fragments landed in buffer KP_NTW & 1 -- move them to buffer 0)
-      bh[0] = bh[KP_NTW & 1];
-      bl[0] = bl[KP_NTW & 1];
       slot3 = slot3 == 2 ? 0 : slot3 + 1;
       tap = ntap; dw = ndw; dh_pitch = ndh; pb = npb;
 #if KP_DIAG & 16
       const unsigned long long t_b0 = KP_T();
 #endif
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // (no drain in front of the barrier: every read of this K-tile's ring slot and of this channel block's patch buffer has
+      // been waited for above; the two tiles in flight belong to the next K-tile and stay in flight across the barrier)
       __builtin_amdgcn_s_barrier();
 #if KP_DIAG & 16
       s_bar += KP_T() - t_b0;
 #endif
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; kt += 3) {
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+      ktile(std::integral_constant<int, 2>{});
     }
+    // the next item's prologue re-issues into buffers 0 and 1: the two reads still in flight must have landed before that
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #if KP_DIAG & 16
     const unsigned long long t_loop1 = KP_T(), r_loop1 = __builtin_amdgcn_s_memrealtime();
     s_loop = t_loop1 - t_loop0;
 #endif
     // (pb has moved on to the buffer that holds the next item's first channel block)
 
-    // ---- epilogue.  C layout: col = lane & 15, row = (lane >> 4) * 4 + reg -- a lane holds FOUR ROWS of one position, and
-    // one 4-byte store per value makes 140 store instructions per lane: measured (in-kernel stamps) 18 k cycles per item, a
-    // quarter of the kernel, store-ISSUE bound.  So every 4 x 4 block (4 lanes of a quad x 4 registers) is transposed inside
-    // its quad with DPP moves: lane t then holds row 4 q + t and FOUR CONSECUTIVE POSITIONS 4 (fr >> 2) .. + 3 of it, and the
-    // tile goes out in 16-byte stores -- a quarter of the instructions, 64-byte runs per row.  (Needs the frame size to be a
-    // multiple of 4 positions, else the four positions may straddle frames: such layers -- 7 x 7 -- keep the scalar stores.)
-    auto out_base = [&](int pos, bool& ok) __attribute__((always_inline)) -> size_t {
-      ok = pos < P;
-      const int pp = ok ? pos : 0;
-      const int f = pp / HW, sp = pp - f * HW;
-      const int nb = f / g.D, d = f - nb * g.D;
-      return ((size_t)nb * g.M * g.D + d) * HW + sp;
+    // ---- epilogue.  The products are issued with the POSITIONS as the MFMA's row operand and the weight rows as its column
+    // operand, so the accumulator tile is the transpose of the usual one: col = lane & 15 is an OUTPUT ROW (channel) and
+    // (lane >> 4) * 4 + reg are FOUR CONSECUTIVE POSITIONS of it -- a lane's four registers are 16 contiguous bytes of the
+    // NCDHW output and go out as one store, no shuffles.  (History, measured with in-kernel stamps: one 4-byte store per value
+    // from the untransposed tile cost 18 k cycles per item, store-issue bound; 16-byte stores behind in-quad DPP transposes
+    // 10.7 k.)  The stores are PLAIN, not streaming: the 64-byte runs of one instruction are half lines, the other half comes
+    // from the next column tile's store, and L2 merges the two before writing back -- with non-temporal stores the halves went
+    // to memory separately (WRITE_SIZE 1.26 x the output bytes; plain stores in this order: 1.002 x, kernel -3.7 %).
+    // Row-tile-outer order so that the two halves of a line are adjacent instructions.  (Frames whose size is not a multiple
+    // of 4 positions -- 7 x 7 -- may straddle a frame inside the four: those layers store value by value.)
+    // Output offsets without divisions: the tile's first position is (frame f_lo, line h_lo, column w_lo); a lane's positions
+    // are reached from there by stepping (frame-internal offset sp, frame of the clip d, clip nb).
+    const int nb_lo = f_lo / g.D, d_lo = f_lo - nb_lo * g.D;      // uniform
+    struct Cur { int sp, d, nb; };
+    auto norm = [&](Cur& c) __attribute__((always_inline)) {
+      while (c.sp >= HW) { c.sp -= HW; if (++c.d == g.D) { c.d = 0; ++c.nb; } }
     };
+    auto offs = [&](const Cur& c) __attribute__((always_inline)) -> size_t {
+      return ((size_t)c.nb * g.M * g.D + c.d) * HW + c.sp;
+    };
+    const int sp_lo = h_lo * W + w_lo;
     const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;     // uniform
     if (vec_ok) {
-      const int tq = fr & 3, cq = fr >> 2;              // my row inside the 4-row group / my group of four positions
-      const bool lo1 = (tq & 1) == 0, lo2 = (tq & 2) == 0;
-      auto xchg = [](float v, int ctrl) __attribute__((always_inline)) -> float {
-        const int vi = __builtin_bit_cast(int, v);
-        return __builtin_bit_cast(float, ctrl == 1 ? __builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xF, 0xF, false)     // lanes t <-> t ^ 1
-                                                   : __builtin_amdgcn_update_dpp(vi, vi, 0x4E, 0xF, 0xF, false));  // lanes t <-> t ^ 2
-      };
+      size_t obase[KP_NTW];
+      bool nok[KP_NTW];
+      {
+        Cur c = {sp_lo + wn * (KP_NTW * 16) + 4 * q, d_lo, nb_lo};
 #pragma unroll
-      for (int j = 0; j < KP_NTW; ++j) {
-        bool nok;
-        const size_t obase = out_base(pos0 + (wn * KP_NTW + j) * 16 + 4 * cq, nok);
+        for (int j = 0; j < KP_NTW; ++j) {
+          norm(c);
+          nok[j] = pos0 + (wn * KP_NTW + j) * 16 + 4 * q < P;
+          obase[j] = offs(c);
+          c.sp += 16;
+        }
+      }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          float r0 = acc[i][j][0], r1 = acc[i][j][1], r2 = acc[i][j][2], r3 = acc[i][j][3];
-          // 2 x 2 blocks: even lanes hand register 1 (3) to their neighbour and take its register 0 (2), and vice versa
-          float y = xchg(lo1 ? r1 : r0, 1);
-          if (lo1) r1 = y; else r0 = y;
-          y = xchg(lo1 ? r3 : r2, 1);
-          if (lo1) r3 = y; else r2 = y;
-          // ... then the 2 x 2 blocks themselves across lanes t <-> t ^ 2: registers (0, 2) and (1, 3)
-          y = xchg(lo2 ? r2 : r0, 2);
-          if (lo2) r2 = y; else r0 = y;
-          y = xchg(lo2 ? r3 : r1, 2);
-          if (lo2) r3 = y; else r1 = y;
-          const int mrow = (mt0 + i) * 16 + q * 4 + tq;
-          const float sc = inva[mrow] * invb;
-          const int m = mblk * BM + mrow;
-          if ((KP_DIAG & 8) && r0 != 12345.f) continue;
-          if (nok && m < g.M) {
-            const f32x4 v = {r0 * sc, r1 * sc, r2 * sc, r3 * sc};
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + obase + (size_t)m * chs));
-          }
+      for (int i = 0; i < NI + XA; ++i) {
+        const int mrow = (i < NI ? (mt0 + i) : (MT - 1)) * 16 + fr;
+        const float sc = inva[mrow] * invb;
+        const int m = mblk * BM + mrow;
+        float* orow = out + (size_t)m * chs;
+#pragma unroll
+        for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
+          const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
+          if ((KP_DIAG & 8) && v[0] != 12345.f) continue;
+          if (nok[j] && m < g.M) *reinterpret_cast<f32x4*>(orow + obase[j]) = v * sc;
         }
       }
     } else {
+      Cur c = {sp_lo + wn * (KP_NTW * 16) + 4 * q, d_lo, nb_lo};
 #pragma unroll
       for (int j = 0; j < KP_NTW; ++j) {
-        bool nok;
-        const size_t obase = out_base(pos0 + (wn * KP_NTW + j) * 16 + fr, nok);
+        size_t ob[4];
+        bool nk[4];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int mrow = (mt0 + i) * 16 + q * 4;
-          const f32x4 ia = *reinterpret_cast<const f32x4*>(&inva[mrow]) * invb;
+        for (int r = 0; r < 4; ++r) {
+          norm(c);
+          nk[r] = pos0 + (wn * KP_NTW + j) * 16 + 4 * q + r < P;
+          ob[r] = offs(c);
+          c.sp += 1;
+        }
+        c.sp += 12;
+#pragma unroll
+        for (int i = 0; i < NI + XA; ++i) {
+          if (i == NI && !(j >= XJ0 && j < XJ0 + XJN)) continue;
+          const int mrow = (i < NI ? (mt0 + i) : (MT - 1)) * 16 + fr;
+          const float sc = inva[mrow] * invb;
+          const int m = mblk * BM + mrow;
+          const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[(i == NI && j >= XJ0 && j < XJ0 + XJN) ? j - XJ0 : 0];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int m = mblk * BM + mrow + r;
-            if ((KP_DIAG & 8) && acc[i][j][r] != 12345.f) continue;
-            if (nok && m < g.M) CSTP_STORE(out + obase + (size_t)m * chs, acc[i][j][r] * ia[r]);
+            if ((KP_DIAG & 8) && v[r] != 12345.f) continue;
+            if (nk[r] && m < g.M) CSTP_STORE(out + ob[r] + (size_t)m * chs, v[r] * sc);
           }
         }
       }
@@ -544,11 +593,12 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 #endif
   }
   };
-  if constexpr (MT - MTW == MTW) {
-    body(std::integral_constant<int, MTW>{});
+  using std::integral_constant;
+  if constexpr (MT % 2 == 0) {
+    body(integral_constant<int, 0>{}, integral_constant<int, 0>{});
   } else {
-    if (wm == 0) body(std::integral_constant<int, MTW>{});
-    else body(std::integral_constant<int, MT - MTW>{});
+    if (wm == 0) body(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    else body(integral_constant<int, 4>{}, integral_constant<int, KP_NTW - 4>{});
   }
 }
 
