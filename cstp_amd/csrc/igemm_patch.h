@@ -18,10 +18,10 @@
 // VALU and no ds_write.  Ring of three K-tiles.
 //
 // Waves: 6, 7 stage the NEXT channel block's patch (gather + split + store, spread over the current block's nine taps); 4, 5 issue
-// the weight DMA two K-tiles ahead (no other memory instruction, so their wait is counted); 0..3 consumers as 2 (rows) x 2 (columns): ceil(MT/2) x 7 accumulator tiles each.  One raw
+// the weight DMA two K-tiles ahead (no other memory instruction, so their wait is counted); 0..3 consumers as 2 (rows) x 2 (columns): MT/2 x 7 accumulator tiles each, an odd last row tile shared by all four.  One raw
 // s_barrier per K-tile.  Blocks are PERSISTENT (one per CU) and the K-tile sequence runs on across a block's work items, so
-// only the first item of a block has an exposed prologue; the consumers fetch the next K-tile's activation fragments (which
-// are in LDS long before) behind the current tile's last products, so only the weight fragments wait for the barrier.
+// only the first item of a block has an exposed prologue; the consumers fetch activation fragments two column tiles ahead (also
+// the next K-tile's, which are in LDS long before), so only the weight fragments wait for the barrier.
 #pragma once
 
 #include <type_traits>
@@ -34,7 +34,7 @@ namespace cstp {
 
 #if KP_DIAG & 16
 // in-kernel stamps of consumer wave 0 of block 0 (diagnostic builds only): [0] cycles in K loops, [1] of them waiting at the
-// barrier (incl. the lgkmcnt drain in front of it), [2] from the top of a K-tile until its weight fragments have landed,
+// barrier, [2] from the top of a K-tile until its weight fragments have landed,
 // [3] epilogue cycles, [4] K-tiles, [5] items, [6] s_memrealtime ticks (100 MHz) over the K loops
 __device__ unsigned long long kp_stamp[8];
 #define KP_T() __builtin_amdgcn_s_memtime()

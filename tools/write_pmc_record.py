@@ -31,7 +31,7 @@ _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, tile), "query")
 out_bytes = 32 * 144 * 16 * 56 * 56 * 4
 in_bytes = 32 * 64 * 16 * 56 * 56 * 4
 rec = {
-    "kernel": "cstp::%s  (S1 spatial convolution forward, 64->144 1x3x3 @16x56x56, 32 clips per launch)" % kernel,
+    "kernel": "%s  (S1 spatial convolution forward, 64->144 1x3x3 @16x56x56, 32 clips per launch)" % kernel,
     "tile": list(tile),
     "tile_note": "cstp_conv3d_query_tile(S1 descriptor, mode 0) when measured: rows, positions, split terms (2 = f16 pair), "
                  "K-tiles per barrier -- bench.py reports `traffic` only while the library still answers this",
