@@ -34,6 +34,7 @@ def trace(path, steps):
     t0 = ends[-steps - 1] if len(ends) > steps else 0
     rows = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
     byk, bys = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
+    pers = defaultdict(list)                       # persistent kernels (one grid for every layer): durations per instantiation
     for r in rows:
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         k = short(r["Kernel_Name"])
@@ -43,6 +44,8 @@ def trace(path, steps):
             key = (k, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]))
             bys[key][0] += 1
             bys[key][1] += us
+            if "igemm_k1p" in k:
+                pers[k].append(us)
     tot = sum(v[1] for v in byk.values())
     print("# %s: last %d steps, %.2f ms of kernels per step" % (path.split("/")[-1], steps, tot / 1e3 / steps))
     print("%-52s %7s %10s %10s %6s" % ("kernel", "calls", "avg_us", "ms/step", "%"))
@@ -52,6 +55,22 @@ def trace(path, steps):
     print("%-52s %9s %4s %7s %10s %10s" % ("kernel", "blocks_x", "gy", "calls", "avg_us", "ms/step"))
     for key, (n, us) in sorted(bys.items(), key=lambda kv: -kv[1][1])[:36]:
         print("%-52s %9d %4d %7d %10.1f %10.2f" % (key[0], key[1], key[2], n, us / n, us / 1e3 / steps))
+    if pers:
+        # the persistent patch kernel launches min(256, items) blocks whatever the layer: tell the layer shapes apart by duration
+        # (a new cluster starts where a launch is > 1.25 x the cluster's shortest)
+        print("\n# persistent patch kernels by duration cluster = per layer shape (S1-size launches are the longest cluster)")
+        print("%-52s %7s %10s %10s %10s" % ("kernel", "calls", "avg_us", "min_us", "max_us"))
+        for k, v in sorted(pers.items()):
+            v.sort()
+            clusters, cur = [], [v[0]]
+            for x in v[1:]:
+                if x > 1.25 * cur[0]:
+                    clusters.append(cur)
+                    cur = []
+                cur.append(x)
+            clusters.append(cur)
+            for c in reversed(clusters):
+                print("%-52s %7d %10.1f %10.1f %10.1f" % (k, len(c), sum(c) / len(c), c[0], c[-1]))
 
 
 if __name__ == "__main__":
