@@ -286,11 +286,15 @@ def main():
                 row["frac_compute"] = row["tflops"] / peak
             else:
                 n, c, s = key[0], key[1], key[2]
-                per_elem = 12.0 if what == "bn_forward" else 20.0      # fwd: x twice + y; bwd: (x, dy) twice + dx
+                # the BN behind S1: its statistics come from the convolution's epilogue when that layer runs the patch kernel
+                pre = what == "bn_forward" and ops.FUSE_BN_STATS and \
+                    lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(ops.ConvDesc(*d_s1)), 2) > 0
+                per_elem = (8.0 if pre else 12.0) if what == "bn_forward" else 20.0      # bwd: (x, dy) twice + dx
                 nbytes = per_elem * n * c * s
                 row.update({"bound": "hbm", "algorithmic_bytes": nbytes,
-                            "bytes_note": "%d B/element: %s" % (per_elem, "statistics pass reads x, apply pass reads x and "
-                                          "writes y" if what == "bn_forward" else "reduction pass reads x and dy, apply pass "
+                            "bytes_note": "%d B/element: %s" % (per_elem, ("statistics from the producing convolution's epilogue; "
+                                          "apply pass reads x and writes y" if pre else "statistics pass reads x, apply pass reads "
+                                          "x and writes y") if what == "bn_forward" else "reduction pass reads x and dy, apply pass "
                                           "reads x and dy and writes dx (ReLU mask recomputed from x)")})
             row["hbm_tbs"] = nbytes / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             row["frac_hbm"] = row["hbm_tbs"] / HBM_PEAK_TBS

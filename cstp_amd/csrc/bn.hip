@@ -142,6 +142,42 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
   if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
 }
 
+// ... the same for MANY partials per channel (the sums a convolution's persistent blocks left: up to 256 per channel and group):
+// one wave per channel, lanes stride over the partials
+__global__ void __launch_bounds__(64)
+bn_finalize_fwd_wide_kernel(const double* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                            float* __restrict__ running_mean, float* __restrict__ running_var, int c, int groups, int nsplit,
+                            double count, float eps, float momentum, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell) {
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  if (ch == 0 && lane == 0 && cell != nullptr) *cell = 0;
+  float rm = 0.f, rv = 0.f;
+  if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+    for (int j = lane; j < nsplit; j += 64) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float isf = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) {
+      save_mean[g * c + ch] = (float)mu;
+      save_invstd[g * c + ch] = isf;
+      if (ss != nullptr) {
+        const float scl = isf * gamma[ch];
+        ss[g * c + ch] = make_float2(scl, beta[ch] - (float)mu * scl);
+      }
+    }
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rm = (float)((1.0 - momentum) * rm + momentum * mu);
+    rv = (float)((1.0 - momentum) * rv + momentum * unb);
+  }
+  if (lane == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+}
+
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
@@ -427,11 +463,36 @@ extern "C" int cstp_bn_forward_train(void* stream, const float* x, const float* 
                                   scale_shift, n, c, s, groups, eps, momentum, relu, ws, ws_bytes, nullptr);
 }
 
+static int bn_forward_train_impl(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                 float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
+                                 float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax,
+                                 const double* pre_part, int32_t pre_nsplit);
+
 extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                                         const float* beta, float* running_mean, float* running_var, float* save_mean,
                                         float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
                                         int32_t groups, float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes,
                                         uint32_t* y_absmax) {
+  return bn_forward_train_impl(stream, x, residual, y, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                               scale_shift, n, c, s, groups, eps, momentum, relu, ws, ws_bytes, y_absmax, nullptr, 0);
+}
+
+extern "C" int cstp_bn_forward_train_pre(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                         float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
+                                         int32_t groups, float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes,
+                                         uint32_t* y_absmax, const double* part, int32_t nsplit) {
+  CSTP_REQUIRE(part != nullptr && nsplit > 0 && s > 1, "precomputed statistics: a partial-sum table from cstp_conv3d_forward_bnstats (BatchNorm3d only)");
+  return bn_forward_train_impl(stream, x, residual, y, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                               scale_shift, n, c, s, groups, eps, momentum, relu, ws, ws_bytes, y_absmax, part, nsplit);
+}
+
+static int bn_forward_train_impl(void* stream, const float* x, const float* residual, float* y, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                 float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
+                                 float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax,
+                                 const double* pre_part, int32_t pre_nsplit) {
   CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd, "null argument");
   CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
   CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
@@ -450,12 +511,19 @@ extern "C" int cstp_bn_forward_train_am(void* stream, const float* x, const floa
   const int ns = bn_nsplit(npg, c);
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
-  else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
-  CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
-                     running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                     reinterpret_cast<float2*>(scale_shift), y_absmax);
+  if (pre_part != nullptr) {
+    // the producing convolution left the sums (cstp_conv3d_forward_bnstats): no pass over x, a wave per channel folds them
+    hipLaunchKernelGGL(bn_finalize_fwd_wide_kernel, dim3(c), dim3(64), 0, st, pre_part, save_mean, save_invstd, running_mean,
+                       running_var, c, groups, pre_nsplit, (double)npg * s, eps, momentum, gamma, beta,
+                       reinterpret_cast<float2*>(scale_shift), y_absmax);
+  } else {
+    if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+    else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+    CSTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
+                       running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
+                       reinterpret_cast<float2*>(scale_shift), y_absmax);
+  }
   CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));

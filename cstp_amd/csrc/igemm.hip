@@ -1091,9 +1091,25 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
 
 // pack the weights for the patch kernel, make sure the gathered tensor's absmax cell is filled, launch it
 // (forward: src = x, Cs = c, M = k;  data gradient: src = dy, Cs = k, M = c -- a 3x3 stride-1 convolution with mirrored taps)
+// BatchNorm partial sums as a by-product of a forward patch launch (igemm_k1p<MT, true>): possible when every 224-position tile
+// is full and lies inside one BN group, the output allows 16-byte stores, and a block meets one row block only
+struct K1pStats { double* part; int groups; };
+static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out);
+static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups) {
+  if (tl.sp != 2 || groups < 1 || groups > 2 || d.n % groups != 0) return 0;
+  const long gpos = (long)(d.n / groups) * d.d * d.h * d.w;
+  if (gpos % KP_NPOS != 0 || ((d.h * d.w) & 3) != 0) return 0;
+  int ntiles, nmblk;
+  const int slots = k1p_grid_slots(d, d.k, tl.mt, &ntiles, &nmblk);
+  if (slots % nmblk != 0) return 0;
+  return 8 * slots / nmblk;
+}
+
 static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
-                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax) {
+                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax, const K1pStats* st = nullptr) {
   PGeom g;
+  g.gpos = st ? (int)((long)(d.n / st->groups) * d.d * d.h * d.w) : 1;
+  g.groups = st ? st->groups : 1;
   g.Cs = dgrad ? d.k : d.c;
   g.ncb = cdiv(g.Cs, 32);
   g.H = d.h; g.W = d.w; g.D = d.d; g.NF = d.n * d.d;
@@ -1109,19 +1125,32 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
-  // persistent blocks, one per CU (the LDS image fills it): 256 of them, or fewer when there is less work
+  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr);
+  dim3 grid((unsigned)(8 * slots), 1, 1);
+  double* part = st ? st->part : nullptr;
+#define CSTP_K1P(MT_) \
+  do { \
+    if (part != nullptr) hipLaunchKernelGGL((igemm_k1p<MT_, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part); \
+    else hipLaunchKernelGGL((igemm_k1p<MT_, false>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part); \
+  } while (0)
+  if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);
+#undef CSTP_K1P
+}
+
+// persistent blocks, one per CU (the LDS image fills it): 256 of them, or fewer when there is less work; returns slots per XCD
+static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out) {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 8 ? n / 8 * 8 : 8;
   }();
+  const long P = (long)d.n * d.d * d.h * d.w;
+  const int ntiles = (int)((P + KP_NPOS - 1) / KP_NPOS), nmblk = cdiv(M, 16 * mt);
+  if (ntiles_out) *ntiles_out = ntiles;
+  if (nmblk_out) *nmblk_out = nmblk;
   const int per_xcd = cdiv(ntiles, 8) * nmblk;        // items of the busiest XCD
   const int slots = per_xcd < n_cu / 8 ? per_xcd : n_cu / 8;
-  dim3 grid((unsigned)(8 * (slots > 0 ? slots : 1)), 1, 1);
-#define CSTP_K1P(MT_) \
-  hipLaunchKernelGGL((igemm_k1p<MT_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk)
-  if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);
-#undef CSTP_K1P
+  return slots > 0 ? slots : 1;
 }
 
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
@@ -1150,6 +1179,34 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
                                    const float* bias, const cstp_in_affine* in_affine, float* y, void* ws,
                                    size_t ws_bytes) {
   return cstp_conv3d_forward_am(stream, desc, x, w, bias, in_affine, y, ws, ws_bytes, nullptr);
+}
+
+extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups) {
+  ConvPlan p;
+  if (desc == nullptr || !make_plan(*desc, p)) return 0;
+  return k1p_stats_nsplit(p.f_t, *desc, groups);
+}
+
+extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y,
+                                           void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, double* part,
+                                           size_t part_bytes, int32_t* nsplit_out) {
+  CSTP_REQUIRE(desc && x && w && y && ws && part && nsplit_out, "null argument");
+  ConvPlan p;
+  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  const int ns = k1p_stats_nsplit(p.f_t, *desc, groups);
+  *nsplit_out = 0;
+  if (ns == 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)       // this layer's kernel cannot deliver the sums: plain forward
+    return cstp_conv3d_forward_am(stream, desc, x, w, nullptr, nullptr, y, ws, ws_bytes, x_absmax);
+  CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
+  CSTP_REQUIRE(part_bytes >= (size_t)desc->k * groups * ns * 2 * sizeof(double), "partial-sum buffer too small");
+  const cstp_conv_desc& d = *desc;
+  CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
+               "tensor too large for 32-bit byte offsets (>= 4 GiB)");
+  const K1pStats st{part, groups};
+  run_k1p(p.f_t, as_stream(stream), d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, &st);
+  CSTP_LAUNCH_CHECK();
+  *nsplit_out = ns;
+  return 0;
 }
 
 extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,

@@ -50,6 +50,8 @@ struct PGeom {
   int H, W, D, NF;  // frame size, frames per clip, frames in total (Nb * D)
   int M;            // valid output rows (channels of `out`)
   int rows_lds;     // LDS rows a tile can touch (<= KP_ROWS)
+  int gpos;         // STATS: output positions per BatchNorm group (a multiple of KP_NPOS: no tile straddles two groups)
+  int groups;       // STATS: BatchNorm groups (<= 2)
 };
 
 // packed weights for igemm_k1p: wpk[mblk][kt = cb * 9 + tap][row (16*MT)][physical chunk (8)][8 f16], row m scaled by a power of
@@ -103,19 +105,24 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
   }
 }
 
-template <int MT>
+// STATS: the forward launch also leaves, per output channel and BatchNorm group, the sums of the outputs and of their squares
+// for the train-mode BatchNorm that consumes them (part[((ch * groups + grp) * nsplit + j) * 2 + {0, 1}], fp64, j = this block's
+// number among the nsplit blocks that own the same row block) -- bn_reduce's pass over the tensor is then not needed.  A lane of
+// the transposed accumulator tile holds 28 values of ONE channel, so the per-item work is 2 FMAs per value, two cross-row adds
+// and one fp64 LDS atomic per lane-channel; the block keeps its sums in LDS across its items and writes them once at the end.
+template <int MT, bool STATS = false>
 __global__ void __launch_bounds__(512, 2)
 igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict__ src, float* __restrict__ out,
-          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk) {
+          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk, double* __restrict__ part) {
   constexpr int BM = 16 * MT;
-  constexpr int MTW = (MT + 1) / 2;                  // row tiles of the first row-wave (the second takes MT - MTW)
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
   constexpr int P_U4 = KP_ROWS * 8;
-  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4)];
+  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
   uint4* const ring = smem;
   uint4* const patch = smem + 3 * A_U4;
   float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);      // [2][BM], by item parity
+  double* const stat_s = reinterpret_cast<double*>(smem + 3 * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -129,7 +136,19 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   tiles_x = tiles_x < 0 ? 0 : (tiles_x < chunk ? tiles_x : chunk);
   const int cnt_x = tiles_x * nmblk;                 // items of this XCD
   const int nitems = slot < cnt_x ? (cnt_x - slot + nslots - 1) / nslots : 0;
-  if (nitems == 0) return;
+  // STATS: this block's slot in the partial-sum table (the host makes nslots a multiple of nmblk, so a block meets one row block only)
+  const int st_mblk = slot % nmblk, st_nsplit = (gridDim.x >> 3) * 8 / nmblk, st_j = xcd * (nslots / nmblk) + slot / nmblk;
+  auto write_part = [&](bool zeros) __attribute__((always_inline)) {
+    for (int e = threadIdx.x; e < g.groups * BM * 2; e += 256) {
+      const int k = e & 1, row = (e >> 1) % BM, grp = (e >> 1) / BM;
+      const int ch = st_mblk * BM + row;
+      if (ch < g.M) part[(((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2 + k] = zeros ? 0.0 : stat_s[(grp * BM + row) * 2 + k];
+    }
+  };
+  if (nitems == 0) {
+    if constexpr (STATS) { if (threadIdx.x < 256) write_part(true); }
+    return;
+  }
   auto item_of = [&](int it, int& tile, int& mblk) __attribute__((always_inline)) {
     const int idx = slot + it * nslots;
     const int t_in = idx / nmblk;
@@ -334,6 +353,9 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
   const int q = lane >> 4;
 
+  if constexpr (STATS) {
+    for (int e = t; e < 2 * BM * 2; e += 256) stat_s[e] = 0.0;       // (consumer threads are t < 256; read many barriers later)
+  }
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
   __builtin_amdgcn_s_setprio(2);                       // the matrix stream outranks the staging waves it shares SIMDs with
 
@@ -389,8 +411,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // accumulators) it hoisted half of each pair to the top of the K-tile and issued the other half right in front of its first
     // use -- seven exposed LDS latencies per K-tile, 22 instead of 16 cycles per MFMA (in-kernel stamps).  LDS operations
     // complete in order, so `lgkmcnt(4)` behind the issue of tile j + 2 means tile j has landed whatever the compiler's own
-    // (weight fragment) reads in between; the loop holds no scalar memory load (they return out of order and would break
-    // the count: checked in the disassembly, tools/check_k1p_isa.sh).
+    // (weight fragment) reads in between.  (Scalar memory loads share the counter and return out of order, but they can only
+    // make this wait longer: of the operations that must have completed to reach the count, at most the scalar ones are not
+    // LDS reads, and the LDS reads among them are the OLDEST ones.  tools/check_k1p_isa.sh lists any that sit among the
+    // products -- there are none in the K loops -- and fails on scratch use.)
     // The tile sequence runs on across K-tiles (7 per K-tile, buffer = sequence number mod 3), so the K-tile loop is
     // unrolled by three -- nkt is a multiple of 9 -- with the buffer phase a compile-time constant.
     f16x8 bh[3], bl[3];
@@ -521,6 +545,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // Output offsets without divisions: the tile's first position is (frame f_lo, line h_lo, column w_lo); a lane's positions
     // are reached from there by stepping (frame-internal offset sp, frame of the clip d, clip nb).
     const int nb_lo = f_lo / g.D, d_lo = f_lo - nb_lo * g.D;      // uniform
+    const int st_grp = STATS ? pos0 / g.gpos : 0;                  // the BatchNorm group this tile belongs to (uniform)
     struct Cur { int sp, d, nb; };
     auto norm = [&](Cur& c) __attribute__((always_inline)) {
       while (c.sp >= HW) { c.sp -= HW; if (++c.d == g.D) { c.d = 0; ++c.nb; } }
@@ -549,11 +574,24 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         const float sc = inva[mrow] * invb;
         const int m = mblk * BM + mrow;
         float* orow = out + (size_t)m * chs;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
           const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
           if ((KP_DIAG & 8) && v[0] != 12345.f) continue;
           if (nok[j] && m < g.M) *reinterpret_cast<f32x4*>(orow + obase[j]) = v * sc;
+          if constexpr (STATS) { s1 += v; s2 += v * v; }     // (every position of every tile is valid: host condition)
+        }
+        if constexpr (STATS) {
+          // my channel's 28 (or 16 / 12) values -> the four lanes that share it (lane, lane ^ 16, ^ 32, ^ 48) -> LDS
+          float a = (s1[0] + s1[1]) + (s1[2] + s1[3]), b = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+          a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+          a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+          if (q == 0 && m < g.M) {
+            double* dst = stat_s + (st_grp * BM + mrow) * 2;
+            __hip_atomic_fetch_add(dst, (double)(a * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 1, (double)(b * sc) * (double)sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     } else {
@@ -599,6 +637,12 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   } else {
     if (wm == 0) body(integral_constant<int, 0>{}, integral_constant<int, 4>{});
     else body(integral_constant<int, 4>{}, integral_constant<int, KP_NTW - 4>{});
+  }
+  if constexpr (STATS) {
+    // the four consumer waves are the block's only live waves here (the others returned behind their last barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write_part(false);
   }
 }
 

@@ -271,6 +271,8 @@ def _queue_join(device: torch.device) -> None:
 # attribute travels with the Python object only: any op in between (reshape, cat, add, an in-place update -- _version is
 # checked) drops it, and the kernels measure for themselves.
 FUSE_ABSMAX = os.environ.get("CSTP_FUSE_ABSMAX", "1") != "0"
+# BatchNorm statistics as a by-product of the producing convolution (patch-kernel layers): 0 keeps the separate pass
+FUSE_BN_STATS = os.environ.get("CSTP_FUSE_BN_STATS", "1") != "0"
 absmax_stats = {"hit": 0, "miss": 0}
 
 
@@ -293,8 +295,10 @@ def _new_cell(like: torch.Tensor) -> Optional[torch.Tensor]:
 
 
 class _Conv3d(torch.autograd.Function):
+    _last_stats = None
+
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding):
+    def forward(ctx, x, w, bias, stride, padding, bn_groups=0):
         lib = _lib.load()
         xam = _absmax_of(x)
         x = _req(x, "conv3d input")
@@ -306,9 +310,22 @@ class _Conv3d(torch.autograd.Function):
         b = None if bias is None else _req(bias, "conv3d bias")
         if AUTOTUNE:
             _autotune(lib, desc, 0, x, w, y, ws)
+        # a train-mode BatchNorm over bn_groups slices of the batch consumes y: where the layer's kernel can, it leaves the
+        # statistics' partial sums beside y (cstp_conv3d_forward_bnstats) and batch_norm_act skips its pass over the tensor
+        ns = lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), bn_groups) if (bn_groups > 0 and b is None and FUSE_BN_STATS) else 0
+        _Conv3d._last_stats = None
         with _span("conv3d_forward", lambda: _desc_key(desc)):
-            check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None,
-                                             y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
+            if ns > 0:
+                part = torch.empty(w.shape[0] * bn_groups * ns * 2, dtype=torch.float64, device=x.device)
+                got = ctypes.c_int32(0)
+                check(lib.cstp_conv3d_forward_bnstats(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _ptr(xam), bn_groups, part.data_ptr(),
+                                                      part.numel() * 8, ctypes.byref(got)), "cstp_conv3d_forward_bnstats")
+                if got.value > 0:
+                    _Conv3d._last_stats = (part, got.value, bn_groups)
+            else:
+                check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None,
+                                                 y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
         ctx.save_for_backward(x, w)
         ctx.x_absmax = xam
         ctx.desc = desc
@@ -378,18 +395,31 @@ class _Conv3d(torch.autograd.Function):
             s = dy.numel() // (n * k)
             db = torch.empty(k, dtype=torch.float32, device=dy.device)
             check(lib.cstp_channel_sum(_stream(), dy.data_ptr(), db.data_ptr(), n, k, s, None, 0), "cstp_channel_sum")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def conv3d(x, w, bias=None, stride=1, padding=0):
-    """F.conv3d drop-in (fp32, NCDHW)."""
-    return _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding))
+def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0):
+    """F.conv3d drop-in (fp32, NCDHW).  ``bn_groups`` > 0: the caller feeds the result to a train-mode ``batch_norm_act`` with
+    that many groups -- the convolution then leaves the BatchNorm's statistics beside its output where its kernel can."""
+    y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups))
+    st = _Conv3d._last_stats
+    _Conv3d._last_stats = None
+    if st is not None:
+        y._cstp_bnstats = st + (y._version,)
+    return y
+
+
+def _bnstats_of(t, groups):
+    tag = getattr(t, "_cstp_bnstats", None)
+    if tag is not None and tag[3] == t._version and tag[2] == groups and tag[0].device == t.device:
+        return tag[0], tag[1]
+    return None
 
 
 def linear(x, w, bias=None):
     """F.linear drop-in for 2-D x: the 1x1x1 convolution over [B][F][1][1][1]."""
     y = _Conv3d.apply(x.reshape(x.shape[0], x.shape[1], 1, 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1, 1), bias,
-                      (1, 1, 1), (0, 0, 0))
+                      (1, 1, 1), (0, 0, 0), 0)
     return y.reshape(x.shape[0], w.shape[0])
 
 
@@ -398,6 +428,7 @@ def linear(x, w, bias=None):
 # ----------------------------------------------------------------------------------------------
 class _BNAct(torch.autograd.Function):
     _last_cell = None
+    _pre_stats = None     # (partial sums, nsplit) the producing convolution left for this call (batch_norm_act sets it)
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
@@ -421,11 +452,20 @@ class _BNAct(torch.autograd.Function):
         remask = relu and res is None and s > 1
         ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device) if remask else None
         cell = _new_cell(x) if s > 1 else None
+        pre = _BNAct._pre_stats
+        _BNAct._pre_stats = None
         with _span("bn_forward", (n, c, s, groups, res is not None, bool(relu))):
-            check(lib.cstp_bn_forward_train_am(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(),
-                                               beta.data_ptr(), _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
-                                               invstd.data_ptr(), _ptr(ss), n, c, s, groups, eps, momentum, 1 if relu else 0,
-                                               ws.data_ptr(), ws.numel(), _ptr(cell)), "cstp_bn_forward_train")
+            if pre is not None and s > 1:
+                check(lib.cstp_bn_forward_train_pre(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(),
+                                                    beta.data_ptr(), _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                                    invstd.data_ptr(), _ptr(ss), n, c, s, groups, eps, momentum,
+                                                    1 if relu else 0, ws.data_ptr(), ws.numel(), _ptr(cell), pre[0].data_ptr(),
+                                                    pre[1]), "cstp_bn_forward_train_pre")
+            else:
+                check(lib.cstp_bn_forward_train_am(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(),
+                                                   beta.data_ptr(), _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                                   invstd.data_ptr(), _ptr(ss), n, c, s, groups, eps, momentum, 1 if relu else 0,
+                                                   ws.data_ptr(), ws.numel(), _ptr(cell)), "cstp_bn_forward_train")
         _BNAct._last_cell = cell     # batch_norm_act hangs it on the tensor object apply() returns
         if remask:
             ctx.save_for_backward(x, ss, gamma, mean, invstd)
@@ -472,6 +512,7 @@ def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual
                    momentum=BN_MOMENTUM, groups=1):
     """y = act(batch_norm_train(x) + residual); running stats updated in place.  ``groups`` > 1: the batch is
     that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
+    _BNAct._pre_stats = _bnstats_of(x, int(groups))
     y = _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
                      int(groups))
     _tag_absmax(y, _BNAct._last_cell)

@@ -89,8 +89,9 @@ class Conv3d(nn.Module):
         self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv3d.reset_parameters
 
-    def forward(self, x):
-        return ops.conv3d(x, self.weight, None, self.stride, self.padding)
+    def forward(self, x, bn_groups=0):
+        """``bn_groups`` > 0: a train-mode BatchNorm with that many groups consumes the result (ops.conv3d)."""
+        return ops.conv3d(x, self.weight, None, self.stride, self.padding, bn_groups)
 
 
 class _BatchNorm(nn.Module):
@@ -205,7 +206,7 @@ class SpatioTemporalConv(nn.Module):
             return self.bn.relu_then(self.temporal_conv, x, groups)
         if pre_bn is not None:
             x = pre_bn(x, relu=True, groups=groups)
-        x = self.bn(self.spatial_conv(x), relu=True, groups=groups)
+        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0), relu=True, groups=groups)
         return self.temporal_conv(x)
 
 

@@ -287,6 +287,83 @@ def test_patch_tile_is_refused_where_the_kernel_does_not_apply():
         del GEOMS["_patch"]
 
 
+# ---- BatchNorm statistics as a by-product of the patch kernel's forward launch -------------------------------------------------
+BNSTAT_GEOMS = {
+    # (x shape, k, row-tile height): positions per BN group are a multiple of 224 in all of them
+    "one row block": ((4, 16, 2, 28, 28), 144, 9),        # 28 tiles over 8 XCDs: XCD 7 owns none (its blocks write zeros)
+    "two row blocks": ((4, 40, 2, 28, 28), 288, 9),       # a block meets one row block only (slots % 2 == 0)
+    "128-row tiles": ((2, 32, 4, 28, 28), 256, 8),
+    "64-row tiles": ((2, 32, 1, 56, 56), 64, 4),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("name", list(BNSTAT_GEOMS))
+def test_patch_kernel_leaves_batchnorm_statistics(name, groups):
+    """conv3d(..., bn_groups) -> batch_norm_act: the BatchNorm takes its sums from the convolution's epilogue
+    (cstp_conv3d_forward_bnstats -> cstp_bn_forward_train_pre) and must equal both the separate-pass result and fp64."""
+    import ctypes
+    from cstp_amd import _lib, ops
+    xs, k, mt = BNSTAT_GEOMS[name]
+    ws = (k, xs[1], 1, 3, 3)
+    lib = _lib.load()
+    ops.set_split_terms(2)
+    ops.set_conv_tile(xs, ws, (1, 1, 1), (0, 1, 1), 0, (2, mt, 0, 0))
+    try:
+        desc = ops._desc(xs, ws, (1, 1, 1), (0, 1, 1))
+        assert lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), groups) > 0
+        assert lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), 3) == 0            # at most two groups
+        g = torch.Generator().manual_seed(5)
+        x = (torch.randn(xs, generator=g) + 0.3).cuda()
+        w = (torch.randn(ws, generator=g) * 0.1).cuda()
+        gamma, beta = (torch.rand(k, generator=g) + 0.5).cuda(), torch.randn(k, generator=g).cuda()
+
+        def run(fused):
+            rm, rv = torch.zeros(k, device="cuda"), torch.ones(k, device="cuda")
+            y = ops.conv3d(x, w, None, 1, (0, 1, 1), bn_groups=groups if fused else 0)
+            assert (getattr(y, "_cstp_bnstats", None) is not None) == fused
+            return ops.batch_norm_act(y, gamma, beta, rm, rv, None, True, 1e-5, 0.1, groups), rm, rv
+
+        a, rma, rva = run(True)
+        b, rmb, rvb = run(False)
+        assert rel_err(a, b) < 2e-6 and rel_err(rma, rmb) < 2e-6 and rel_err(rva, rvb) < 2e-6
+        # fp64 truth
+        yc = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (0, 1, 1))
+        outs, rm, rv = [], torch.zeros(k, dtype=torch.float64), torch.ones(k, dtype=torch.float64)
+        for part in yc.chunk(groups, 0):
+            outs.append(F.relu(F.batch_norm(part, rm, rv, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)))
+        ref = torch.cat(outs, 0)
+        assert rel_err(a.cpu().double(), ref) < 1e-4
+        assert rel_err(rma.cpu().double(), rm) < 1e-4 and rel_err(rva.cpu().double(), rv) < 1e-4
+    finally:
+        ops.set_split_terms(0)
+
+
+@pytest.mark.gpu
+def test_batchnorm_statistics_by_product_is_declined_where_it_cannot_be_exact():
+    """Tiles that straddle two BN groups, a gather-kernel tile, or frames that rule out 16-byte stores: nsplit = 0 and the
+    call is the plain forward (BatchNorm then makes its own pass)."""
+    import ctypes
+    from cstp_amd import _lib, ops
+    lib = _lib.load()
+    ops.set_split_terms(2)
+    try:
+        for xs, k, tile, groups in (((2, 16, 1, 14, 14), 144, (2, 9, 0, 0), 2),      # 196 positions per group
+                                    ((4, 16, 2, 28, 28), 144, (1, 9, 0, 0), 2),      # gather kernel pinned
+                                    ((2, 16, 32, 7, 7), 144, (2, 9, 0, 0), 1)):      # 7 x 7 frames (1568 = 7 * 224, but 49 % 4 != 0)
+            ws = (k, xs[1], 1, 3, 3)
+            ops.set_conv_tile(xs, ws, (1, 1, 1), (0, 1, 1), 0, tile)
+            desc = ops._desc(xs, ws, (1, 1, 1), (0, 1, 1))
+            assert lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), groups) == 0
+            x, w = torch.randn(xs, device="cuda"), torch.randn(ws, device="cuda") * 0.1
+            y = ops.conv3d(x, w, None, 1, (0, 1, 1), bn_groups=groups)
+            assert getattr(y, "_cstp_bnstats", None) is None
+            assert rel_err(y, ops.conv3d(x, w, None, 1, (0, 1, 1))) == 0.0
+    finally:
+        ops.set_split_terms(0)
+
+
 # ---- weight gradient: accumulation into the caller's buffer, and the deterministic (two-stage split-K) mode -------------------
 def _wgrad_call(lib, ops, desc, x, dy, dw, accumulate):
     import ctypes
