@@ -53,6 +53,36 @@ def test_argument_validation_without_gpu():
     assert lib.cstp_ntxent_workspace_bytes(32, 512) >= (2 * 32 + 2 * 32 * 32) * 4
 
 
+def test_every_bn_entry_point_fails_cleanly_on_its_early_return_path():
+    """The precondition checks of the BatchNorm entry points (train, train with by-products, precomputed statistics, statistics only,
+    eval, backward) return an error code and a readable message before any HIP call -- the path on which round 1's first GPU run
+    once died inside the error formatting.  Null pointers, bad shapes, a missing workspace: no GPU needed."""
+    from cstp_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(8)          # any non-null address: never dereferenced before the checks fail
+    f = ctypes.c_float
+    calls = [
+        ("cstp_bn_forward_train", (None,) * 11 + (4, 8, 16, 1, f(1e-5), f(0.1), 0, None, 0), b"null argument"),
+        ("cstp_bn_forward_train", (None, one, None, one, one, one, None, None, one, one, None, 4, 8, 16, 3, f(1e-5), f(0.1), 0, None, 0),
+         b"bad shape"),
+        ("cstp_bn_forward_train", (None, one, None, one, one, one, None, None, one, one, None, 1, 8, 1, 1, f(1e-5), f(0.1), 0, None, 0),
+         b"more than 1 value"),
+        ("cstp_bn_forward_train", (None, one, None, one, one, one, None, None, one, one, None, 4, 8, 16, 1, f(1e-5), f(0.1), 0, None, 0),
+         b"workspace too small"),
+        ("cstp_bn_forward_train_pre", (None, one, None, one, one, one, None, None, one, one, None, 4, 8, 16, 1, f(1e-5), f(0.1), 0, one,
+                                       1 << 20, None, None, 0), b"precomputed statistics"),
+        ("cstp_bn_stats_train", (None,) * 9 + (4, 8, 16, 1, f(1e-5), f(0.1), None, 0), b"null argument"),
+        ("cstp_bn_stats_train", (None, one, one, one, None, None, one, one, one, 4, 8, 1, 1, f(1e-5), f(0.1), one, 1 << 20), b"bad shape"),
+        ("cstp_bn_stats_train", (None, one, one, one, one, None, one, one, one, 4, 8, 16, 1, f(1e-5), f(0.1), one, 1 << 20),
+         b"running stats must come as a pair"),
+    ]
+    for name, args, needle in calls:
+        rc = getattr(lib, name)(*args)
+        msg = lib.cstp_last_error()
+        assert rc != 0 and needle in msg, (name, rc, msg)
+        assert b"line" in msg                                   # the fixed "<text> (line N)" format
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from cstp_amd import _lib, ops
