@@ -14,7 +14,7 @@ src, dst = sys.argv[1], sys.argv[2]
 commit = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("CSTP_COMMIT", "unknown")
 vals, kernel = {}, None
 for line in open(src):
-    m = re.match(r"(void \S+)\s+(\w+)\s+n=\s*\d+\s+last4 avg ([\d.e+]+)", line)
+    m = re.match(r"(void .+?)\s{2,}(\w+)\s+n=\s*\d+\s+last4 avg ([\d.e+]+)", line)
     if m and "igemm" in m.group(1):
         kernel = kernel or m.group(1).replace("void ", "")
         if m.group(1).replace("void ", "") == kernel:
@@ -31,7 +31,8 @@ _lib.check(lib.cstp_conv3d_query_tile(ctypes.byref(desc), 0, tile), "query")
 out_bytes = 32 * 144 * 16 * 56 * 56 * 4
 in_bytes = 32 * 64 * 16 * 56 * 56 * 4
 rec = {
-    "kernel": "%s  (S1 spatial convolution forward, 64->144 1x3x3 @16x56x56, 32 clips per launch)" % kernel,
+    "kernel": "%s  (S1 spatial convolution forward, 64->144 1x3x3 @16x56x56, 32 clips per launch; the <.., true> instantiation also "
+              "leaves the per-channel sums for the BatchNorm behind it, as in the training step)" % kernel,
     "tile": list(tile),
     "tile_note": "cstp_conv3d_query_tile(S1 descriptor, mode 0) when measured: rows, positions, split terms (2 = f16 pair), "
                  "K-tiles per barrier -- bench.py reports `traffic` only while the library still answers this",
