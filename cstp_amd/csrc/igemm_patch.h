@@ -207,7 +207,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   if (wave >= 6) {
     // ============================================ patch staging waves (6, 7) ============================================
     // Wave 6 gathers channels 0..15 of each 32-channel block, wave 7 channels 16..31; lane l owns LDS rows l + 64 r.  They share
-    // their SIMDs with the second row-wave's consumers (waves 2, 3), which own one row tile fewer when MT is odd.  Seven rounds
+    // their SIMDs with the second row-wave's consumers (waves 2, 3).  Seven rounds
     // of (16 dword gathers -> split -> four 16-byte LDS stores) stage the NEXT channel block's patch while the current one is
     // multiplied (schedule below).  No load is conditional -- a round with nothing to stage
     // gathers through out-of-range offsets (zeros, no memory traffic) -- so the compiler's s_waitcnt accounting keeps two
