@@ -294,6 +294,7 @@ BNSTAT_GEOMS = {
     "two row blocks": ((4, 40, 2, 28, 28), 288, 9),       # a block meets one row block only (slots % 2 == 0)
     "128-row tiles": ((2, 32, 4, 28, 28), 256, 8),
     "64-row tiles": ((2, 32, 1, 56, 56), 64, 4),
+    "ragged rows": ((4, 16, 2, 28, 28), 136, 9),          # 136 channels in a 144-row block: the padded rows leave no sums
 }
 
 
