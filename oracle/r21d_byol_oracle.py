@@ -350,13 +350,20 @@ def loss_total(loss_byol, logits, labels, loss_weight):
 
 
 def train_step(sd, mom, x1, x2, labels, layer_sizes, lr, momentum=0.9, weight_decay=0.0,
-               loss_weight=(0.1, 1, 1, 1, 1), clip=True):
-    """One optimisation step.  ``sd`` tensors are mutated/replaced; ``mom`` is the SGD momentum dict."""
+               loss_weight=(0.1, 1, 1, 1, 1), clip=True, ntxent_weight=0.0, temperature=0.5):
+    """One optimisation step.  ``sd`` tensors are mutated/replaced; ``mom`` is the SGD momentum dict.
+    ``ntxent_weight`` != 0: BASELINE configs[1]'s objective -- the criterion main_byol.py:191-197 builds,
+    NTXentLoss(zis = online projection of clip 1, zjs = of clip 2), is added to the loss_weight sum and its gradient
+    flows into the projector and the online encoder."""
     keys = trainable_keys(layer_sizes)
     for k in keys:
         sd[k] = sd[k].detach().requires_grad_(True)
     loss_byol, logits, extras = model_forward(sd, x1, x2, layer_sizes, True)
     total, ce = loss_total(loss_byol, logits, labels, loss_weight)
+    nt = None
+    if ntxent_weight != 0.0:
+        nt = ntxent(extras["proj_1"], extras["proj_2"], temperature)
+        total = total + ntxent_weight * nt
     grads = torch.autograd.grad(total, [sd[k] for k in keys])
     gnorm = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads))
     coef = 1.0
@@ -380,6 +387,8 @@ def train_step(sd, mom, x1, x2, labels, layer_sizes, lr, momentum=0.9, weight_de
         "logits": [l.detach() for l in logits], "grad_norm": gnorm.detach(), "grads": out_grads,
     }
     info.update({k: v.detach() for k, v in extras.items()})
+    if nt is not None:
+        info["ntxent"] = nt.detach()
     return info
 
 

@@ -49,8 +49,17 @@ CONFIGS = {
     "d1_heavy": (1, 4, 8, 56, 1, 0.05, 5e-4),
     "r18_heavy": (18, 4, 8, 56, 1, 0.05, 5e-4),
     "r34_heavy": (34, 8, 8, 64, 1, 0.05, 5e-4),
+    # BASELINE configs[1]'s REAL objective at its clip shape (B = 4): "NT-Xent + overlap-rate head only" -- the reference
+    # module's loss_com outputs with loss_weight (0.1, 1, 1, 0, 0) PLUS 1 x the reference's own NTXentLoss on the two online
+    # projections, built as main_byol.py:191-197 builds it (batch_size = the batch, --temperature default 0.5, cosine).  The
+    # projections are taken from the module's own forward by a hook on online_net.project, so NT-Xent's gradient flows into
+    # the projector and the whole online encoder exactly as if the driver had added the term.  (d1_ntx: the same on depth 1.)
+    "r18_cfg2nt": (18, 4, 16, 112, 1, 0.05, 5e-4),
+    "d1_ntx": (1, 4, 8, 56, 2, 0.005, 5e-4),
 }
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 1.0, 1.0)
+# name: (loss_weight, NT-Xent weight, temperature)
+NTX = {"r18_cfg2nt": ((0.1, 1.0, 1.0, 0.0, 0.0), 1.0, 0.5), "d1_ntx": ((0.1, 1.0, 1.0, 0.0, 0.0), 1.0, 0.5)}
 
 
 def build_reference(layer_sizes, dtype, heavy=False):
@@ -86,8 +95,13 @@ def run_config(name):
     crit = torch.nn.CrossEntropyLoss()
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=wd)
     names = [k for k, _ in model.named_parameters()]
+    w, ntw, tau = NTX.get(name, (LOSS_WEIGHT, 0.0, 0.5))
     out = {"meta": np.array([depth, b, t, hw, steps], dtype=np.int64), "heavy": np.array(int(heavy)), "lr": np.array(lr), "wd": np.array(wd),
-           "loss_weight": np.array(LOSS_WEIGHT)}
+           "loss_weight": np.array(w), "ntxent_weight": np.array(ntw), "temperature": np.array(tau)}
+    projs = []
+    if ntw:
+        model.online_net.project.register_forward_hook(lambda mod, inp, outp: projs.append(outp))
+        crit_ctr = NTXentLoss(device="cpu", batch_size=b, temperature=tau, use_cosine_similarity=True)
     for step in range(1, steps + 1):
         t0 = time.time()
         # capture forward internals through hooks-free re-computation: run pieces as forward does
@@ -95,9 +109,14 @@ def run_config(name):
         loss_byol = loss_byol.mean()
         ce = [crit(logits[0], labels["spa"]), crit(logits[1], labels["tem"]), crit(logits[2], labels["pb"]),
               crit(logits[3], labels["pb"]), crit(logits[4], labels["rot1"]), crit(logits[5], labels["rot2"])]
-        w = LOSS_WEIGHT
         total = (w[0] * loss_byol + w[1] * ce[0] + w[2] * ce[1] + w[3] * ce[2] + w[3] * ce[3]
                  + w[4] * ce[4] + w[4] * ce[5])
+        if ntw:
+            z1, z2 = projs          # online_net(x1), online_net(x2) in forward order (r21d_byol.py:359-360)
+            del projs[:]
+            nt = crit_ctr(z1, z2)
+            out["s%d.ntxent" % step] = np.array(float(nt))
+            total = total + ntw * nt
         opt.zero_grad()
         total.backward()
         gn = {k: float(p.grad.detach().norm()) for k, p in model.named_parameters() if p.grad is not None}

@@ -123,12 +123,12 @@ def run_config(name):
     print("wrote", name)
 
 
-def run_backbone50():
-    """Depth 50: the reference WRAPPER is shape-broken (view(-1, 512) of 2048 features, r3d_byol.py:204), its BACKBONE
+def run_backbone50(name="r3d_50_backbone", b=4, t=8, hw=64):
+    """``r3d_50_backbone_224`` (round 3): the same at BASELINE configs[4]'s TRUE clip shape, 3x16x224x224 (B = 2: fp64 memory).
+    Depth 50: the reference WRAPPER is shape-broken (view(-1, 512) of 2048 features, r3d_byol.py:204), its BACKBONE
     modules are not.  Drive ResNet(Bottleneck, [3, 4, 6, 3]) layer by layer up to the average pool (the statements of
     ResNet.forward :193-203 without the broken view) in train mode, fp64: pooled features of two clip batches, and the
     per-tensor gradient norms of  sum(features * c)  for a closed-form c -- pins Bottleneck forward and backward."""
-    b, t, hw = 4, 8, 64
     net = ref_model.resnet50(sample_size=hw, sample_duration=t, shortcut_type="B", num_classes=101)
     layers = r3d.for_depth(50)
     sd = r3d.closed_form_state(r3d.encoder_spec("online_net", layers), torch.float64)
@@ -157,8 +157,8 @@ def run_backbone50():
         out["feat_2"] = backbone(x2).numpy().astype(np.float32)
         net.eval()
         out["feat_eval"] = backbone(x1).numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "r3d_50_backbone.npz"), **out)
-    print("wrote r3d_50_backbone", out["feat_1"].shape)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, out["feat_1"].shape)
 
 
 if __name__ == "__main__":
@@ -166,5 +166,7 @@ if __name__ == "__main__":
     for c in (sys.argv[1:] or list(CONFIGS) + ["r3d_50_backbone"]):
         if c == "r3d_50_backbone":
             run_backbone50()
+        elif c == "r3d_50_backbone_224":
+            run_backbone50(c, 2, 16, 224)
         else:
             run_config(c)

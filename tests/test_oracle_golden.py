@@ -67,6 +67,11 @@ def is_heavy(g):
     return bool(int(g["heavy"])) if "heavy" in g.files else False
 
 
+def ntx_weight(g):
+    """fixtures written since round 3 may carry the NT-Xent term of BASELINE configs[1] (make_golden.py: NTX)"""
+    return float(g["ntxent_weight"]) if "ntxent_weight" in g.files else 0.0
+
+
 def run_oracle(name, steps=None):
     g = load(name)
     depth, b, t, hw, nsteps = [int(v) for v in g["meta"]]
@@ -78,7 +83,8 @@ def run_oracle(name, steps=None):
     keys = [str(k) for k in g["state_keys"]]
     pkeys = [str(k) for k in g["param_keys"]]
     for _ in range(nsteps):
-        info = orc.train_step(sd, mom, x1, x2, labels, ls, float(g["lr"]), 0.9, float(g["wd"]), tuple(g["loss_weight"]), True)
+        info = orc.train_step(sd, mom, x1, x2, labels, ls, float(g["lr"]), 0.9, float(g["wd"]), tuple(g["loss_weight"]), True,
+                              ntxent_weight=ntx_weight(g), temperature=float(g["temperature"]) if "temperature" in g.files else 0.5)
         infos.append(info)
         states.append(state_checksums(sd, keys))
         moms.append(np.array([[float(mom[k].double().sum()), float(mom[k].double().abs().sum())] if k in mom else [0.0, 0.0]
@@ -87,7 +93,7 @@ def run_oracle(name, steps=None):
 
 
 @pytest.mark.parametrize("name", ["d1_small", "r18_small", "r34_small", "d1_cfg1", "d1_heavy", "r18_heavy", "r34_heavy",
-                                  "r34_cfg4"])
+                                  "r34_cfg4", "d1_ntx"])
 def test_oracle_matches_reference_golden(name):
     g, infos, states, moms, pkeys = run_oracle(name)
     for s, info in enumerate(infos, start=1):
@@ -100,6 +106,8 @@ def test_oracle_matches_reference_golden(name):
         assert rel([float(c) for c in info["ce"]], g[pre + "ce"]) < tol
         assert rel(float(info["grad_norm"]), g[pre + "grad_norm"]) < gtol
         assert rel(torch.stack(info["logits"]).numpy(), g[pre + "logits"]) < tol
+        if ntx_weight(g):
+            assert rel(float(info["ntxent"]), g[pre + "ntxent"]) < tol
         gn = np.array([float(info["grads"][k].norm()) if k in info["grads"] else -1.0 for k in pkeys])
         assert rel(gn, g[pre + "grad_norms"]) < gtol
         assert cs_err(states[s - 1], g[pre + "state_cs"]) < STATE_TOLS[s] * STATE_SCALE.get(name, 1.0)
