@@ -171,8 +171,10 @@ def test_r3d_finetune_and_test_drivers(tmp_path, capsys):
     assert 0.0 <= acc <= 1.0 and "Video accuracy" in capsys.readouterr().out
 
 
-def test_r3d_50_bottleneck_backbone_matches_reference_modules_and_corrected_wrapper_matches_oracle():
-    """BASELINE configs[4] names 3D-ResNet-50.  (1) The Bottleneck BACKBONE on the HIP kernels against the reference's own layers
+@pytest.mark.parametrize("fixture", ["r3d_50_backbone", "r3d_50_backbone_224"])
+def test_r3d_50_bottleneck_backbone_matches_reference_modules_and_corrected_wrapper_matches_oracle(fixture):
+    """``r3d_50_backbone_224``: the same at BASELINE configs[4]'s TRUE clip shape, 3x16x224x224 (B = 2: fp64 memory).
+    BASELINE configs[4] names 3D-ResNet-50.  (1) The Bottleneck BACKBONE on the HIP kernels against the reference's own layers
     driven up to the average pool in fp64 (tests/golden/r3d_50_backbone.npz): pooled 2048-d features of two clip batches, the
     per-tensor gradient norms of sum(features * c), the BN running statistics, and the eval-mode features.  (2) The WRAPPER at
     this depth follows the corrected spec of cstp_amd/r3d_byol.py (the reference's is shape-broken, r3d_byol.py:204) and is
@@ -182,7 +184,7 @@ def test_r3d_50_bottleneck_backbone_matches_reference_modules_and_corrected_wrap
     from cstp_amd.train import PretrainStep
     from oracle import r21d_byol_oracle as orc
     from oracle import r3d_byol_oracle as r3d
-    g = load("r3d_50_backbone")
+    g = load(fixture)
     depth, b, t, hw, _ = [int(v) for v in g["meta"]]
     layers = r3d.for_depth(depth)
     try:
@@ -238,3 +240,41 @@ def test_r3d_50_bottleneck_backbone_matches_reference_modules_and_corrected_wrap
             assert rel(msd[k].cpu().numpy(), osd[k].detach().numpy()) < 2e-3, k
     finally:
         r3d.for_depth(18)
+
+
+def test_full_size_properties_r3d50_cfg5_share():
+    """BASELINE configs[4] at its full per-GPU share -- 3D-ResNet-50 (corrected wrapper), 4 clip pairs of 3x16x224x224 (B = 32
+    over 8 GPUs), fp32 storage -- one optimisation step of the product's PretrainStep, checked through properties that need
+    no oracle run (the Bottleneck backbone itself is pinned at this clip shape by ``r3d_50_backbone_224``)."""
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r3d_byol import R3DBYOL
+    from cstp_amd.synthetic import device_batch
+    from cstp_amd.train import PretrainStep
+    torch.manual_seed(1)
+    model = R3DBYOL(pretrain=True, opts=_opts(50, 16, 224)).cuda()
+    a = model.flatten_parameters()
+    model.train()
+    lr, wd = 0.01, 5e-4
+    opt = FlatSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=wd, arenas=a)
+    step = PretrainStep(model, opt, (0.1, 1.0, 1.0, 1.0, 1.0), clip_grad_norm=True)
+    x1, x2, lab = device_batch(4, 16, 224, torch.device("cuda"), seed=1)
+    t_before, q_before, p_before = a["target"].clone(), a["param"][:a["n_encoder"]].clone(), a["param"].clone()
+    out = step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+    torch.cuda.synchronize()
+    # (1) shapes of the corrected wrapper (B rows, 5/5/4/4-way heads), everything finite, BYOL loss in [0, 8]
+    assert [tuple(l.shape) for l in out.logits] == [(4, 5), (4, 5), (4, 4), (4, 4), (4, 4), (4, 4)]
+    assert np.isfinite(float(out.loss_total)) and 0.0 <= float(out.loss_byol) <= 8.0
+    assert bool(torch.isfinite(a["grad"]).all()) and bool(torch.isfinite(a["param"]).all())
+    # (2) the EMA is linear in the PRE-step online weights (it runs before the optimiser step, r3d_byol.py:392-395)
+    expect = t_before * 0.996 + q_before * (1.0 - 0.996)
+    assert rel_err(a["target"], expect) < 1e-6
+    # (3) first SGD step: p_new = p - lr * (clip * g + wd * p); .grad holds the clipped gradient
+    gnorm = float(out.grad_norm)
+    coef = min(1.0, 18.0 / (gnorm + 1e-6))
+    total_norm = float(a["grad"].double().norm())
+    assert abs(total_norm - gnorm * coef) / (gnorm * coef) < 1e-4
+    assert rel_err(a["param"], p_before - lr * (a["grad"] + wd * p_before)) < 1e-5
+    # (4) BN counters and running statistics moved: two forwards per network per step
+    msd = model.state_dict()
+    assert int(msd["online_net.bn1.num_batches_tracked"]) == 2 and int(msd["target_net.bn1.num_batches_tracked"]) == 2
+    assert bool(torch.isfinite(a["buffers"]).all()) and float(a["buffers"].abs().sum()) > 0

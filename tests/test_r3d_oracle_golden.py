@@ -95,10 +95,12 @@ def test_r3d_module_state_dict_contract_and_errors():
     assert m(torch.zeros(1), torch.zeros(1), o_type="nonsense") is None
 
 
-def test_r3d_50_backbone_oracle_matches_reference_modules():
-    """Depth 50: the reference's Bottleneck BACKBONE driven layer by layer (its wrapper is shape-broken, r3d_byol.py:204) pins the
+@pytest.mark.parametrize("fixture", ["r3d_50_backbone", "r3d_50_backbone_224"])
+def test_r3d_50_backbone_oracle_matches_reference_modules(fixture):
+    """``r3d_50_backbone_224``: BASELINE configs[4]'s true clip shape, 3x16x224x224 (B = 2).
+    Depth 50: the reference's Bottleneck BACKBONE driven layer by layer (its wrapper is shape-broken, r3d_byol.py:204) pins the
     oracle's encoder forward and backward; the wrapper around it follows the corrected spec and is parity-unpinned."""
-    g = load("r3d_50_backbone")
+    g = load(fixture)
     depth, b, t, hw, _ = [int(v) for v in g["meta"]]
     layers = r3d.for_depth(depth)
     try:
