@@ -716,6 +716,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 }  // namespace cstp
 #include "igemm_split.h"
 #include "igemm_patch.h"
+#include "igemm_wpatch.h"
 namespace cstp {
 
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
@@ -745,6 +746,15 @@ static bool patch_geom_ok(const cstp_conv_desc& d) {
     return false;
   if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
   return patch_rows_needed(d.n * d.d, d.h, d.w) <= KP_ROWS;
+}
+// the weight-gradient patch kernel igemm_k2p (igemm_wpatch.h): the same layers; its x ring holds 2 * (W + 2) + 34 rows <= 7 segments
+static bool wpatch_geom_ok(const cstp_conv_desc& d) {
+  if (!(d.kt == 1 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 1 && d.pw == 1))
+    return false;
+  if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
+  // (stream rows and frame counts stay below 2^25 and the divisors below 129: the kernel divides by multiplication)
+  if ((long)d.n * d.d * (d.h + 1) * (d.w + 2) >= (1l << 25) || d.h + 1 > 128 || d.d > 128) return false;
+  return 2 * (d.w + 2) + 34 <= 7 * 32;
 }
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
@@ -826,7 +836,7 @@ struct ConvPlan {
   // dgrad
   Tile d_t; int d_Cp, d_Mp, d_Kp;
   // wgrad
-  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split;
+  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split; bool w_patch;
 };
 
 static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
@@ -869,14 +879,20 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   p.w_mt = (CSTP_M16 && !p.w_straddle && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);   // 9 = nine 16-row tiles
   p.w_blocks = 2048;   // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set
   p.w_split = false;
+  p.w_patch = false;
   {
     Tile wt;
     bool have_wt = lookup_tuned(d, 2, wt);
     // developer override: CSTP_WTILE="s<mt>,<blocks/256>" forces the split weight-gradient kernel; unset in production
     static const char* wov = getenv("CSTP_WTILE");
+    if (!have_wt && wov != nullptr && wov[0] == 'p') { wt = Tile{9, 1, 0, 0, 2}; have_wt = true; }
     if (!have_wt && wov != nullptr && wov[0] == 's') {
       int mt = 0, bl = 8;
       if (sscanf(wov + 1, "%d,%d", &mt, &bl) >= 1 && (mt == 4 || mt == 8 || mt == 9)) { wt = Tile{mt, bl, 0, 0, 1}; have_wt = true; }
+    }
+    if (have_wt && wt.sp == 2) {       // igemm_k2p: x resident in LDS across the nine taps (144-row blocks, f16 pair)
+      p.w_patch = !p.w_straddle && x_small && y_small && wpatch_geom_ok(d);
+      have_wt = false;
     }
     if (have_wt) {
       p.w_mt = wt.m16 ? 9 : wt.mt;
@@ -1153,6 +1169,41 @@ static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_ou
   return slots > 0 ? slots : 1;
 }
 
+static int cu_count() {
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n / 8 * 8 : 8;
+  }();
+  return n_cu;
+}
+
+// weight gradient on the LDS-resident x ring (igemm_k2p): one block per (144-row block, 32-channel block, frame range);
+// fills the packed slab(s) like igemm_k2s (scaled sums; unpack_wgrad_kernel applies the inverse operand scales)
+static int run_k2p(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, const float* x, const float* dy, float* dwp,
+                   const unsigned* xcell, const unsigned* dycell, bool det, size_t det_stride, int* nslabs_out) {
+  WPGeom g;
+  g.C = d.c; g.M = d.k;
+  g.ncb = cdiv(d.c, 32); g.nmblk = cdiv(d.k, WP_BM);
+  g.H = d.h; g.W = d.w; g.D = d.d; g.NF = d.n * d.d;
+  g.lead = cdiv(2 * (d.w + 2) + 34, 32);
+  g.Jp = p.w_Jp; g.Cp = p.w_Cp;
+  g.mg_pitch = (unsigned)((1ull << 32) / (unsigned)(d.w + 2) + 1);
+  g.mg_hp1 = (unsigned)((1ull << 32) / (unsigned)(d.h + 1) + 1);
+  g.mg_d = (unsigned)((1ull << 32) / (unsigned)d.d + 1);
+  const int ncombo = g.ncb * g.nmblk;
+  int ns = cu_count() / ncombo;
+  if (ns < 1) ns = 1;
+  if (ns > g.NF) ns = g.NF;
+  if (det && ns > DET_MAX_SPLITS) ns = DET_MAX_SPLITS;
+  g.fper = cdiv(g.NF, ns);
+  g.nsplit = cdiv(g.NF, g.fper);
+  dim3 grid((unsigned)align_up((size_t)ncombo * g.nsplit, 8), 1, 1);
+  hipLaunchKernelGGL(igemm_k2p, grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0);
+  *nslabs_out = det ? g.nsplit : 1;
+  return 0;
+}
+
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
 struct InAffine { const float2* ss; int npg, groups, relu; };
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
@@ -1353,6 +1404,28 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
   g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
+  if (p.w_patch && ia.ss == nullptr) {
+    // igemm_k2p.  Slab(s) + absmax cells zeroed together; in deterministic mode one slab per frame-range split.
+    const size_t det_stride_p = det ? slab_al / sizeof(float) : 0;
+    int ns_max = cu_count() / (cdiv(d.c, 32) * cdiv(d.k, WP_BM));
+    ns_max = ns_max < 1 ? 1 : (ns_max > DET_MAX_SPLITS ? DET_MAX_SPLITS : ns_max);
+    const size_t slabs_bytes_p = slab_al * (det ? ns_max : 1);
+    unsigned* cells_p = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + slabs_bytes_p);
+    if (hipMemsetAsync(dwp, 0, slabs_bytes_p + 256, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+    const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
+    if (x_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(nx)), dim3(256), 0, s, x, nx, cells_p);
+    if (dy_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s, dy, ny, cells_p + 1);
+    const unsigned* xc = x_absmax != nullptr ? x_absmax : cells_p;
+    const unsigned* dyc = dy_absmax != nullptr ? dy_absmax : cells_p + 1;
+    int nslabs = 1;
+    run_k2p(s, d, p, x, dy, dwp, xc, dyc, det, det_stride_p, &nslabs);
+    CSTP_LAUNCH_CHECK();
+    const size_t tot_p = (size_t)d.k * d.c * p.ntaps;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot_p)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp,
+                       xc, dyc, nslabs, det_stride_p, accumulate ? 1 : 0);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   // the split kernel has no fused input transform: a call that carries one runs the native kernel with its analytic tile
   const bool w_split = p.w_split && ia.ss == nullptr;
   if (p.w_split && !w_split) p.w_mt = (CSTP_M16 && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);
@@ -1414,6 +1487,10 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  if (mode == 2 && p.w_patch) {       // igemm_k2p: 144 rows x (32 channels x 9 taps), f16 pair
+    out4[0] = WP_BM; out4[1] = 288; out4[2] = 2; out4[3] = 0;
+    return 0;
+  }
   if (mode == 2) {
     out4[0] = p.w_split ? 16 * p.w_mt : (p.w_mt == 9 ? 144 : 32 * p.w_mt);
     out4[1] = 128;
@@ -1470,7 +1547,10 @@ extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, co
   if (mode == 2) {
     const int blocks = tile4[2];
     CSTP_REQUIRE(blocks >= 1 && blocks <= 64, "split-K block target / 256 out of range");
-    if (split) {
+    if (split == 2) {
+      CSTP_REQUIRE(mt == 9, "patch weight-gradient tile: 9 row tiles of 16");
+      t = Tile{9, 1, 0, 0, 2};
+    } else if (split) {
       CSTP_REQUIRE(mt == 4 || mt == 8 || mt == 9, "split weight-gradient tiles: 4, 8 or 9 row tiles of 16");
       t = Tile{mt, blocks, 0, 0, 1};
     } else {
@@ -1536,6 +1616,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
       if (cdiv(d.k, 144) * 144 - d.k < pad) smt = 9;
       for (int blocks = 4; blocks <= 16; blocks *= 2) wc[nw++] = Tile{smt, blocks, 0, 0, 1};
     }
+    if (allow_split2 && !stem && wpatch_geom_ok(d)) wc[nw++] = Tile{9, 1, 0, 0, 2};      // igemm_k2p
     hipStream_t s2 = as_stream(stream);
     hipEvent_t a0, a1;
     if (hipEventCreate(&a0) != hipSuccess || hipEventCreate(&a1) != hipSuccess) return fail("hipEventCreate failed%s", "");

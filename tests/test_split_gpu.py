@@ -287,6 +287,55 @@ def test_patch_tile_is_refused_where_the_kernel_does_not_apply():
         del GEOMS["_patch"]
 
 
+# ---- the weight gradient on the LDS-resident x ring, igemm_k2p (csrc/igemm_wpatch.h): the same layers ------------------------
+WPATCH_GEOMS = dict(PATCH_GEOMS)
+WPATCH_GEOMS.update({
+    "S5": ((2, 256, 2, 14, 14), 576),       # 8 channel blocks x 4 row blocks: more (row, channel) pairs than frames per block
+    "wide": ((1, 32, 3, 6, 90), 48),        # W = 90: the widest frame whose two halo lines still fit the 7 ring segments
+    "one frame": ((1, 32, 1, 28, 28), 144), # a single frame: more blocks than frames (the surplus blocks return at once)
+})
+
+
+@pytest.mark.parametrize("name", list(WPATCH_GEOMS))
+def test_patch_kernel_weight_gradient(name):
+    from cstp_amd import ops
+    xs, k = WPATCH_GEOMS[name]
+    GEOMS["_wpatch"] = (xs, k, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.set_split_terms(2)
+    try:
+        _run("_wpatch", {0: (0, 2, 1, 1), 1: (0, 2, 1, 1), 2: (2, 9, 1, 0)})
+        import ctypes
+        from cstp_amd import _lib
+        out = (ctypes.c_int32 * 4)()
+        desc = ops._desc(xs, (k, xs[1], 1, 3, 3), (1, 1, 1), (0, 1, 1))
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(desc), 2, out), "query")
+        assert list(out)[:3] == [144, 288, 2]                # the pinned patch kernel is what runs
+        tile = (ctypes.c_int32 * 4)()
+        _lib.check(_lib.load().cstp_conv3d_get_tile(ctypes.byref(desc), 2, tile), "get")
+        assert list(tile)[:2] == [2, 9]
+        for sx, sw, sdy in ((1e-20, 1.0, 1e10), (3e18, 1e-12, 1e-10)):
+            _run("_wpatch", {2: (2, 9, 1, 0)}, scale_x=sx, scale_w=sw, scale_dy=sdy)
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_wpatch"]
+
+
+def test_patch_weight_gradient_is_refused_where_the_kernel_does_not_apply():
+    """Pinned on a strided / temporal / too-wide / bf16-triple call it falls back to another kernel at call time."""
+    from cstp_amd import ops
+    for name in ("S2s", "T1", "odd"):
+        _run(name, {2: (2, 9, 1, 0)})
+    GEOMS["_wpatch"] = ((1, 16, 1, 4, 100), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))       # W = 100 > 93
+    try:
+        _run("_wpatch", {2: (2, 9, 1, 0)})
+        GEOMS["_wpatch"] = PATCH_GEOMS["S1"] + ((1, 3, 3), (1, 1, 1), (0, 1, 1))
+        ops.set_split_terms(3)
+        _run("_wpatch", {2: (2, 9, 1, 0)})
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_wpatch"]
+
+
 # ---- BatchNorm statistics as a by-product of the patch kernel's forward launch -------------------------------------------------
 BNSTAT_GEOMS = {
     # (x shape, k, row-tile height): positions per BN group are a multiple of 224 in all of them
@@ -374,7 +423,7 @@ def _wgrad_call(lib, ops, desc, x, dy, dw, accumulate):
               "cstp_conv3d_backward_weight_acc")
 
 
-@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (0, 3, 4, 0)], ids=["split", "native"])
+@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (0, 3, 4, 0), (2, 9, 1, 0)], ids=["split", "native", "patch"])
 def test_weight_gradient_accumulate_flag(tile):
     from cstp_amd import _lib, ops
     lib = _lib.load()
@@ -394,7 +443,8 @@ def test_weight_gradient_accumulate_flag(tile):
     assert rel_err(dw, w.grad) < TOL                             # dw = gradient
 
 
-@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (1, 4, 16, 0), (0, 3, 4, 0), (0, 9, 8, 0)], ids=["split9", "split4", "native3", "native144"])
+@pytest.mark.parametrize("tile", [(1, 9, 8, 0), (1, 4, 16, 0), (0, 3, 4, 0), (0, 9, 8, 0), (2, 9, 1, 0)],
+                         ids=["split9", "split4", "native3", "native144", "patch"])
 def test_deterministic_weight_gradient_is_bit_reproducible(tile):
     """CSTP_DETERMINISTIC / cstp_set_deterministic: per-split slabs summed in a fixed order instead of f32 atomics -- the same
     inputs give the same bits, and the result keeps the parity bar."""

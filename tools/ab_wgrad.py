@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the weight-gradient kernel the library picks (persisted table / pinned tile) on the layer shapes of R(2+1)D-18 at the
-cfg2 batch -- for A/B-ing library variants (CSTP_LIB_PATH).  usage: ab_wgrad.py [layer ...]"""
+cfg2 batch -- for A/B-ing library variants (CSTP_LIB_PATH).  usage: ab_wgrad.py [tile=sp,mt,blocks,0] [layer ...]
+(tile=2,9,1,0 pins the LDS-resident-x kernel igemm_k2p, tile=1,9,8,0 the gather kernel igemm_k2s)"""
 import ctypes
 import os
 import sys
@@ -15,7 +16,9 @@ LAYERS = {"S1": ((32, 64, 16, 56, 56), 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)), "T
           "S5": ((32, 256, 4, 14, 14), 576, (1, 3, 3), (1, 1, 1), (0, 1, 1)), "T5": ((32, 576, 4, 14, 14), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))}
 lib = ops._lib.load()
 st = torch.cuda.current_stream().cuda_stream
-for name in (sys.argv[1:] or list(LAYERS)):
+PIN = [tuple(int(v) for v in a[5:].split(",")) for a in sys.argv[1:] if a.startswith("tile=")]
+NAMES = [a for a in sys.argv[1:] if not a.startswith("tile=")]
+for name in (NAMES or list(LAYERS)):
     xs, k, ks, stride, pad = LAYERS[name]
     ws = (k, xs[1]) + ks
     x = torch.randn(xs, device="cuda")
@@ -23,7 +26,10 @@ for name in (sys.argv[1:] or list(LAYERS)):
     dw = torch.empty(ws, device="cuda")
     desc = ops._desc(xs, ws, stride, pad)
     wsb = torch.empty(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device="cuda")
-    ops._autotune(lib, desc, 2, x, dy, dw, wsb)
+    if PIN:
+        ops.set_conv_tile(xs, ws, stride, pad, 2, PIN[0])
+    else:
+        ops._autotune(lib, desc, 2, x, dy, dw, wsb)
     xc, dc = x.abs().max().view(torch.int32).clone(), dy.abs().max().view(torch.int32).clone()
     fn = lambda: ops.check(lib.cstp_conv3d_backward_weight_am(st, ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(), dw.data_ptr(),
                                                               wsb.data_ptr(), wsb.numel(), xc.data_ptr(), dc.data_ptr()), "wgrad")
