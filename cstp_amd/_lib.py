@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ConvDesc(ctypes.Structure):
@@ -62,7 +62,7 @@ SIGNATURES = {
     "cstp_bn_forward_train_pre": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                             c_float, c_float, c_int32, _P, c_size_t, _P, _P, c_int32]),
     "cstp_conv3d_bnstats_nsplit": (c_int32, [POINTER(ConvDesc), c_int32]),
-    "cstp_conv3d_forward_bnstats": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, c_int32, _P, c_size_t,
+    "cstp_conv3d_forward_bnstats": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, c_int32, _P, _P, c_size_t,
                                               POINTER(c_int32)]),
     "cstp_bn_backward_am": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, _P, c_size_t, _P, c_int32]),

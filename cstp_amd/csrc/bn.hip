@@ -153,14 +153,17 @@ bn_finalize_fwd_wide_kernel(const double* __restrict__ part, float* __restrict__
   if (ch == 0 && lane == 0 && cell != nullptr) *cell = 0;
   float rm = 0.f, rv = 0.f;
   if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  // the partials are sums of (x - pivot) and (x - pivot)^2; the pivot the producing launch used sits behind them
+  const double pivot = part[(size_t)c * groups * nsplit * 2 + ch];
   for (int g = 0; g < groups; ++g) {
     double s0 = 0.0, s1 = 0.0;
     const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
     for (int j = lane; j < nsplit; j += 64) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
-    const double mu = s0 / count;
-    double var = s1 / count - mu * mu;
+    const double dm = s0 / count;
+    const double mu = pivot + dm;
+    double var = s1 / count - dm * dm;
     if (var < 0.0) var = 0.0;
     const float isf = (float)(1.0 / sqrt(var + (double)eps));
     if (lane == 0) {

@@ -1109,7 +1109,7 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
 // (forward: src = x, Cs = c, M = k;  data gradient: src = dy, Cs = k, M = c -- a 3x3 stride-1 convolution with mirrored taps)
 // BatchNorm partial sums as a by-product of a forward patch launch (igemm_k1p<MT, true>): possible when every 224-position tile
 // is full and lies inside one BN group, the output allows 16-byte stores, and a block meets one row block only
-struct K1pStats { double* part; int groups; };
+struct K1pStats { double* part; int groups; const float* pivot; };
 static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out);
 static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups) {
   if (tl.sp != 2 || groups < 1 || groups > 2 || d.n % groups != 0) return 0;
@@ -1144,10 +1144,11 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr);
   dim3 grid((unsigned)(8 * slots), 1, 1);
   double* part = st ? st->part : nullptr;
+  const float* pivot = st ? st->pivot : nullptr;
 #define CSTP_K1P(MT_) \
   do { \
-    if (part != nullptr) hipLaunchKernelGGL((igemm_k1p<MT_, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part); \
-    else hipLaunchKernelGGL((igemm_k1p<MT_, false>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part); \
+    if (part != nullptr) hipLaunchKernelGGL((igemm_k1p<MT_, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot); \
+    else hipLaunchKernelGGL((igemm_k1p<MT_, false>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot); \
   } while (0)
   if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);
 #undef CSTP_K1P
@@ -1239,8 +1240,8 @@ extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_
 }
 
 extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y,
-                                           void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, double* part,
-                                           size_t part_bytes, int32_t* nsplit_out) {
+                                           void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot,
+                                           double* part, size_t part_bytes, int32_t* nsplit_out) {
   CSTP_REQUIRE(desc && x && w && y && ws && part && nsplit_out, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1249,11 +1250,11 @@ extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* d
   if (ns == 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)       // this layer's kernel cannot deliver the sums: plain forward
     return cstp_conv3d_forward_am(stream, desc, x, w, nullptr, nullptr, y, ws, ws_bytes, x_absmax);
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
-  CSTP_REQUIRE(part_bytes >= (size_t)desc->k * groups * ns * 2 * sizeof(double), "partial-sum buffer too small");
+  CSTP_REQUIRE(part_bytes >= ((size_t)desc->k * groups * ns * 2 + desc->k) * sizeof(double), "partial-sum buffer too small");
   const cstp_conv_desc& d = *desc;
   CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
-  const K1pStats st{part, groups};
+  const K1pStats st{part, groups, pivot};
   run_k1p(p.f_t, as_stream(stream), d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, &st);
   CSTP_LAUNCH_CHECK();
   *nsplit_out = ns;

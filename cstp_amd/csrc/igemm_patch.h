@@ -107,13 +107,18 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
 
 // STATS: the forward launch also leaves, per output channel and BatchNorm group, the sums of the outputs and of their squares
 // for the train-mode BatchNorm that consumes them (part[((ch * groups + grp) * nsplit + j) * 2 + {0, 1}], fp64, j = this block's
-// number among the nsplit blocks that own the same row block) -- bn_reduce's pass over the tensor is then not needed.  A lane of
+// number among the nsplit blocks that own the same row block) -- bn_reduce's pass over the tensor is then not needed.  The sums
+// are taken around a per-channel PIVOT c (the caller's guess of the mean: the BatchNorm's running mean; null = 0):
+// sum(y - c) and sum((y - c)^2), c stored behind the partials.  The fp32 roundings of the per-lane partial sums (28 values
+// and their squares before the sums go to fp64) are then relative to the spread of the channel around c instead of to its
+// magnitude, and var = E[(y-c)^2] - (E[y-c])^2 no longer cancels for channels with |mean| >> std (round-2 ADVICE).  A lane of
 // the transposed accumulator tile holds 28 values of ONE channel, so the per-item work is 2 FMAs per value, two cross-row adds
 // and one fp64 LDS atomic per lane-channel; the block keeps its sums in LDS across its items and writes them once at the end.
 template <int MT, bool STATS = false>
 __global__ void __launch_bounds__(512, 2)
 igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict__ src, float* __restrict__ out,
-          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk, double* __restrict__ part) {
+          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk, double* __restrict__ part,
+          const float* __restrict__ pivot) {
   constexpr int BM = 16 * MT;
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
@@ -143,6 +148,14 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       const int k = e & 1, row = (e >> 1) % BM, grp = (e >> 1) / BM;
       const int ch = st_mblk * BM + row;
       if (ch < g.M) part[(((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2 + k] = zeros ? 0.0 : stat_s[(grp * BM + row) * 2 + k];
+    }
+    // the pivot the sums are taken around rides behind the partials (one writer per row block), so that the fold works with
+    // exactly the value this launch used
+    if (st_j == 0) {
+      for (int row = threadIdx.x; row < BM; row += 256) {
+        const int ch = st_mblk * BM + row;
+        if (ch < g.M) part[(size_t)g.M * g.groups * st_nsplit * 2 + ch] = pivot != nullptr ? (double)pivot[ch] : 0.0;
+      }
     }
   };
   if (nitems == 0) {
@@ -575,12 +588,14 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         const int m = mblk * BM + mrow;
         float* orow = out + (size_t)m * chs;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        float pv = 0.f;                                  // STATS: the pivot in accumulator units (y = v * sc)
+        if constexpr (STATS) { if (pivot != nullptr && m < g.M) pv = pivot[m] / sc; }
 #pragma unroll
         for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
           const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
           if ((KP_DIAG & 8) && v[0] != 12345.f) continue;
           if (nok[j] && m < g.M) *reinterpret_cast<f32x4*>(orow + obase[j]) = v * sc;
-          if constexpr (STATS) { s1 += v; s2 += v * v; }     // (every position of every tile is valid: host condition)
+          if constexpr (STATS) { const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv; }     // (every position of every tile is valid: host condition)
         }
         if constexpr (STATS) {
           // my channel's 28 (or 16 / 12) values -> the four lanes that share it (lane, lane ^ 16, ^ 32, ^ 48) -> LDS

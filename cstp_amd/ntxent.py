@@ -21,10 +21,29 @@ def all_gather_with_grad(z: torch.Tensor) -> torch.Tensor:
     """cat over ranks of z (rank-major); gradient flows into the local slice only."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return z
-    parts = [torch.empty_like(z) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, z.detach().contiguous())
-    parts[dist.get_rank()] = z
-    return torch.cat(parts, dim=0)
+    world, rank, b = dist.get_world_size(), dist.get_rank(), z.shape[0]
+    # ONE collective straight into the [world * B, F] result (no per-rank allocations, no cat); the local slice is then put
+    # back as the live tensor so that the gradient reaches this rank's embeddings
+    out = torch.empty((world * b,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+    zc = z.detach().contiguous()
+    try:
+        dist.all_gather_into_tensor(out, zc)
+    except (RuntimeError, NotImplementedError):          # a backend without the tensor form
+        dist.all_gather(list(out.split(b, dim=0)), zc)
+    return _PutLocal.apply(out, z, rank * b)
+
+
+class _PutLocal(torch.autograd.Function):
+    """gathered[off : off + B] <- z, with d(out)/dz = that slice of the incoming gradient (the other rows are constants)."""
+
+    @staticmethod
+    def forward(ctx, gathered, z, off):
+        ctx.off, ctx.b = off, z.shape[0]
+        return gathered.view_as(gathered)      # (already holds z's values in its slice: the all-gather wrote them)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[ctx.off:ctx.off + ctx.b], None
 
 
 class NTXentLoss(torch.nn.Module):

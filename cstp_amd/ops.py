@@ -117,20 +117,39 @@ def _load_table():
     return _table
 
 
+def _is_rank0() -> bool:
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def save_tune_table(path=None) -> bool:
-    """Write the table (atomically) if it has new entries; silently skipped on a read-only tree."""
+    """Write the table (atomically) if it has new entries: on RANK 0 only, merged over what is on disk (another job may have
+    added geometries meanwhile), once per call -- the training steps call it after their first step, and an exit hook
+    covers everything else.  (Round 2 rewrote the file from every rank on every newly timed geometry: last writer won.)
+    Silently skipped on a read-only tree."""
     global _table_dirty
     path = path or TUNE_TABLE_PATH
     if path is None or _table is None or not _table_dirty or os.environ.get("CSTP_TUNE_TABLE_RO", "0") == "1":
         return False
+    if not _is_rank0():
+        return False
     import json
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
+        merged = {}
+        try:
+            with open(path) as f:
+                data = json.load(f)
+            if data.get("arch") == "gfx950" and data.get("abi") == _lib.ABI_VERSION and data.get("rev") == TUNE_REV:
+                merged = {k: [int(v) for v in t] for k, t in data.get("tiles", {}).items()}
+        except (OSError, ValueError, AttributeError):
+            merged = {}
+        merged.update(_table)
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "w") as f:
             json.dump({"arch": "gfx950", "abi": _lib.ABI_VERSION, "rev": TUNE_REV,
                        "key": "arithmetic|mode|" + ",".join(f for f, _ in ConvDesc._fields_),
-                       "tile": "cstp_conv3d_set_tile encoding", "tiles": dict(sorted(_table.items()))}, f, indent=0)
+                       "tile": "cstp_conv3d_set_tile encoding", "tiles": dict(sorted(merged.items()))}, f, indent=0)
         os.replace(tmp, path)
         _table_dirty = False
         return True
@@ -164,16 +183,24 @@ def _autotune(lib, desc, mode, src, w, out, ws):
     check(lib.cstp_conv3d_get_tile(ctypes.byref(desc), mode, arr), "cstp_conv3d_get_tile")
     if arr[0] >= 0:
         tbl[sk] = [int(v) for v in arr]
-        _table_dirty = True
-        save_tune_table()
+        _table_dirty = True          # written by save_tune_table(): after a step's first call, or at exit
+
+
+import atexit  # noqa: E402
+
+atexit.register(save_tune_table)
 
 
 def share_tune_table(src: int = 0) -> None:
     """Rank ``src``'s tuned tiles -> every rank (one broadcast of a small dict), so that all ranks of a job run the same
-    kernel for the same layer even when some geometry had to be timed in this run.  No-op without a process group."""
+    kernel for the same layer even when some geometry had to be timed in this run; rank 0 then persists the table.
+    Without a process group: only the save."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        save_tune_table()
         return
+    if dist.get_rank() == src:
+        save_tune_table()
     lib = _lib.load()
     box = [dict(_load_table()) if dist.get_rank() == src else None]
     dist.broadcast_object_list(box, src=src)
@@ -232,9 +259,25 @@ def conv_out_shape(x_shape, w_shape, stride, padding):
 # ----------------------------------------------------------------------------------------------
 # weight gradients on a side stream
 # ----------------------------------------------------------------------------------------------
-# DIRECT_WGRAD is switched on by the training steps (cstp_amd.train) when the parameters' .grad tensors are views of the
-# flat gradient arena and nothing hooks their autograd accumulation (the flat all-reduce path, or no DDP at all).
-DIRECT_WGRAD = False
+# A parameter is tagged ``_cstp_direct_grad`` by the training steps (cstp_amd.train -> mark_direct_grad) when its .grad tensor
+# is a view of its model's flat gradient arena and nothing hooks its autograd accumulation (the flat all-reduce path, or no
+# DDP at all): the kernels then add the gradient into the arena themselves and autograd sees None.  The tag is a property
+# of the PARAMETER (of one model), not of the process: a second model in the same process -- DDP with its bucket reducer,
+# anything that relies on gradient hooks -- is not affected (round-2 ADVICE).
+def mark_direct_grad(model, arenas, on: bool) -> None:
+    lo = hi = 0
+    if arenas is not None:
+        g = arenas["grad"]
+        lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+    for p in model.parameters():
+        ok = bool(on) and p.grad is not None and lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous()
+        p._cstp_direct_grad = ok
+
+
+def _direct(p) -> bool:
+    return getattr(p, "_cstp_direct_grad", False) and p.is_leaf and p.grad is not None
+
+
 OVERLAP_WGRAD = os.environ.get("CSTP_OVERLAP_WGRAD", "1") == "1"
 _side_streams = {}
 _join_pending = set()
@@ -298,9 +341,10 @@ class _Conv3d(torch.autograd.Function):
     _last_stats = None
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, bn_groups=0):
+    def forward(ctx, x, w, bias, stride, padding, bn_groups=0, bn_pivot=None):
         lib = _lib.load()
         xam = _absmax_of(x)
+        w_in = w
         x = _req(x, "conv3d input")
         w = _req(w, "conv3d weight")
         desc = _desc(x.shape, w.shape, stride, padding)
@@ -316,10 +360,13 @@ class _Conv3d(torch.autograd.Function):
         _Conv3d._last_stats = None
         with _span("conv3d_forward", lambda: _desc_key(desc)):
             if ns > 0:
-                part = torch.empty(w.shape[0] * bn_groups * ns * 2, dtype=torch.float64, device=x.device)
+                part = torch.empty(w.shape[0] * bn_groups * ns * 2 + w.shape[0], dtype=torch.float64, device=x.device)
                 got = ctypes.c_int32(0)
+                pv = None if bn_pivot is None else _req(bn_pivot, "BatchNorm pivot")
+                if pv is not None and pv.numel() != w.shape[0]:
+                    raise _lib.CstpError("BatchNorm pivot has %d entries for %d output channels" % (pv.numel(), w.shape[0]))
                 check(lib.cstp_conv3d_forward_bnstats(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), _ptr(xam), bn_groups, part.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _ptr(xam), bn_groups, _ptr(pv), part.data_ptr(),
                                                       part.numel() * 8, ctypes.byref(got)), "cstp_conv3d_forward_bnstats")
                 if got.value > 0:
                     _Conv3d._last_stats = (part, got.value, bn_groups)
@@ -327,6 +374,7 @@ class _Conv3d(torch.autograd.Function):
                 check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None,
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
         ctx.save_for_backward(x, w)
+        ctx.w_param = w_in           # the parameter object itself (save_for_backward hands back a new tensor object)
         ctx.x_absmax = xam
         ctx.desc = desc
         ctx.has_bias = bias is not None
@@ -347,7 +395,7 @@ class _Conv3d(torch.autograd.Function):
         # autograd sees None for this input.  With OVERLAP_WGRAD it also runs on a second HIP stream: it feeds nothing
         # downstream in the backward chain, so the matrix-core-bound weight-gradient kernels execute beside the HBM-bound
         # BatchNorm backward kernels of the main chain (the arena is joined before anything reads it, _join_side_streams).
-        direct_w = ctx.needs_input_grad[1] and DIRECT_WGRAD and w.is_leaf and w.grad is not None and w.grad.is_contiguous()
+        direct_w = ctx.needs_input_grad[1] and _direct(ctx.w_param)
         side_w = direct_w and OVERLAP_WGRAD and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] > 1
 
         def wgrad_into_arena():
@@ -356,8 +404,8 @@ class _Conv3d(torch.autograd.Function):
                 _autotune(lib, desc, 2, x, dy, torch.empty_like(w), wsx)          # (tuning overwrites its output)
             with _span("conv3d_backward_weight", lambda: _desc_key(desc)):
                 check(lib.cstp_conv3d_backward_weight_acc(_stream(), ctypes.byref(desc), x.data_ptr(), None, dy.data_ptr(),
-                                                          w.grad.data_ptr(), wsx.data_ptr(), wsx.numel(), _ptr(xam), _ptr(dyam),
-                                                          1), "cstp_conv3d_backward_weight")
+                                                          ctx.w_param.grad.data_ptr(), wsx.data_ptr(), wsx.numel(), _ptr(xam),
+                                                          _ptr(dyam), 1), "cstp_conv3d_backward_weight")
 
         if side_w:
             main = torch.cuda.current_stream(x.device)
@@ -395,13 +443,14 @@ class _Conv3d(torch.autograd.Function):
             s = dy.numel() // (n * k)
             db = torch.empty(k, dtype=torch.float32, device=dy.device)
             check(lib.cstp_channel_sum(_stream(), dy.data_ptr(), db.data_ptr(), n, k, s, None, 0), "cstp_channel_sum")
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0):
+def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None):
     """F.conv3d drop-in (fp32, NCDHW).  ``bn_groups`` > 0: the caller feeds the result to a train-mode ``batch_norm_act`` with
-    that many groups -- the convolution then leaves the BatchNorm's statistics beside its output where its kernel can."""
-    y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups))
+    that many groups -- the convolution then leaves the BatchNorm's statistics beside its output where its kernel can.
+    ``bn_pivot`` ([C_out], e.g. that BatchNorm's running_mean): the sums are taken around it (cstp_conv3d_forward_bnstats)."""
+    y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups), bn_pivot)
     st = _Conv3d._last_stats
     _Conv3d._last_stats = None
     if st is not None:
@@ -419,7 +468,7 @@ def _bnstats_of(t, groups):
 def linear(x, w, bias=None):
     """F.linear drop-in for 2-D x: the 1x1x1 convolution over [B][F][1][1][1]."""
     y = _Conv3d.apply(x.reshape(x.shape[0], x.shape[1], 1, 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1, 1), bias,
-                      (1, 1, 1), (0, 0, 0), 0)
+                      (1, 1, 1), (0, 0, 0), 0, None)
     return y.reshape(x.shape[0], w.shape[0])
 
 
@@ -490,8 +539,7 @@ class _BNAct(torch.autograd.Function):
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         # parameters whose .grad is a live slice of the flat gradient arena (cstp_amd.train): the kernel adds into it directly
         pg, pb = ctx.params
-        direct = DIRECT_WGRAD and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and pg.is_leaf and pb.is_leaf \
-            and pg.grad is not None and pb.grad is not None and pg.grad.is_contiguous() and pb.grad.is_contiguous()
+        direct = ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _direct(pg) and _direct(pb)
         dgamma = pg.grad if direct else torch.empty_like(gamma)
         dbeta = pb.grad if direct else torch.empty_like(gamma)
         nbytes = lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)

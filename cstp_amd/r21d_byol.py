@@ -89,9 +89,10 @@ class Conv3d(nn.Module):
         self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv3d.reset_parameters
 
-    def forward(self, x, bn_groups=0):
-        """``bn_groups`` > 0: a train-mode BatchNorm with that many groups consumes the result (ops.conv3d)."""
-        return ops.conv3d(x, self.weight, None, self.stride, self.padding, bn_groups)
+    def forward(self, x, bn_groups=0, bn_pivot=None):
+        """``bn_groups`` > 0: a train-mode BatchNorm with that many groups consumes the result; ``bn_pivot``: its running
+        mean, the value its statistics are summed around (ops.conv3d)."""
+        return ops.conv3d(x, self.weight, None, self.stride, self.padding, bn_groups, bn_pivot)
 
 
 class _BatchNorm(nn.Module):
@@ -206,7 +207,7 @@ class SpatioTemporalConv(nn.Module):
             return self.bn.relu_then(self.temporal_conv, x, groups)
         if pre_bn is not None:
             x = pre_bn(x, relu=True, groups=groups)
-        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0), relu=True, groups=groups)
+        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean), relu=True, groups=groups)
         return self.temporal_conv(x)
 
 
@@ -283,17 +284,28 @@ class R2Plus1DNet(nn.Module):
         if self.proj_flag:
             self.project = Projector(dim=512, projection_size=512, projection_hidden_size=4096)
 
-    def forward(self, x, groups=1, after_conv2=None):
+    # gradient stages in the order the backward pass completes them (ByolBase.grad_stage_slices): everything behind the
+    # encoder's last stage, then conv5 .. conv2, then the stem
+    GRAD_STAGES = ("head", "conv5", "conv4", "conv3", "conv2", "stem")
+
+    def forward(self, x, groups=1, after_conv2=None, stage_done=None):
         """``groups`` > 1: x holds that many independent forward calls back to back along the batch axis
         (BN statistics stay per call); convolutions are per-sample, so the result equals separate calls.
-        ``after_conv2``: called once the conv2 stage is enqueued (R21DBYOL starts the target network's stream there)."""
-        x = self.bn1(self.conv1(x, groups), relu=True, groups=groups)
-        x = self.conv2(x, groups)
+        ``after_conv2``: called once the conv2 stage is enqueued (R21DBYOL starts the target network's stream there).
+        ``stage_done(i)``: called DURING BACKWARD when the gradient of stage i's input exists, i.e. when every parameter
+        gradient of GRAD_STAGES[i] (and of the stages before it) has been enqueued -- the data-parallel step starts that
+        slice's all-reduce there instead of after the whole backward pass (cstp_amd.train.StagedAllReduce)."""
+        def mark(t, i):
+            if stage_done is not None and t.requires_grad:
+                t.register_hook(lambda g, i=i: stage_done(i))
+            return t
+        x = mark(self.bn1(self.conv1(x, groups), relu=True, groups=groups), 4)      # conv2's input: conv2 is complete
+        x = mark(self.conv2(x, groups), 3)
         if after_conv2 is not None:
             after_conv2()
-        x = self.conv3(x, groups)
-        x = self.conv4(x, groups)
-        x = self.conv5(x, groups)
+        x = mark(self.conv3(x, groups), 2)
+        x = mark(self.conv4(x, groups), 1)
+        x = mark(self.conv5(x, groups), 0)                                         # projector, predictor, heads are complete
         x = ops.global_avg_pool(x)  # AdaptiveAvgPool3d(1) + view(-1, 512)
         if self.proj_flag:
             return x, self.project(x, groups)
@@ -306,6 +318,36 @@ class ByolBase(nn.Module):
     ``target_net`` (pretrain), ``pretrain`` and ``_head_bn_calls()``."""
 
     _arenas = None
+    _grad_stage_cb = None      # set by the data-parallel training step: called with a stage index during backward
+
+    def grad_stage_slices(self):
+        """[(offset, numel)] of the flat gradient arena per gradient stage, in the order the backward pass completes them
+        (R2Plus1DNet.GRAD_STAGES): [project | predictor | heads], conv5, conv4, conv3, conv2, stem.  parameters() order is
+        module registration order, so every stage is one contiguous run of the arena; together they tile it exactly.
+        None when the model has no arenas or its encoder does not mark stages (the step then reduces the arena in one piece)."""
+        net = self.online_net
+        if self._arenas is None or not hasattr(net, "GRAD_STAGES") or not getattr(net, "proj_flag", False):
+            return None
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.trainable_parameters()]
+        owner = {}
+        for name in ("conv1", "bn1"):
+            for p in getattr(net, name).parameters():
+                owner[id(p)] = 5
+        for i, name in ((4, "conv2"), (3, "conv3"), (2, "conv4"), (1, "conv5")):
+            for p in getattr(net, name).parameters():
+                owner[id(p)] = i
+        runs, off = [], 0
+        for p, n in zip(self.trainable_parameters(), sizes):
+            st = owner.get(id(p), 0)           # projector, predictor, heads
+            if runs and runs[-1][0] == st:
+                runs[-1][2] += n
+            else:
+                runs.append([st, off, n])
+            off += n
+        if sorted(r[0] for r in runs) != list(range(6)) or off != self._arenas["grad"].numel():
+            return None                        # a stage is not contiguous: fall back to the flat reduce
+        by_stage = {r[0]: (r[1], r[2]) for r in runs}
+        return [by_stage[i] for i in range(6)]
 
     def _head_bn_calls(self):
         """[(module holding BatchNorms outside the two encoders, forward calls per training step)] (pretrain only)."""
@@ -533,14 +575,15 @@ class R21DBYOL(ByolBase):
                         _, target_proj = self.target_net(x, groups=2)
                         tgt["swapped"] = torch.cat((target_proj[b:], target_proj[:b]), dim=0).detach()
 
-                online_feat, online_proj = self.online_net(x, groups=2, after_conv2=start_target)
+                online_feat, online_proj = self.online_net(x, groups=2, after_conv2=start_target,
+                                                           stage_done=self._grad_stage_cb)
                 online_pred = self.predictor(online_proj, groups=2)
                 main.wait_stream(side)
                 target_swapped = tgt["swapped"]
                 target_swapped.record_stream(main)
                 x.record_stream(side)
             else:
-                online_feat, online_proj = self.online_net(x, groups=2)
+                online_feat, online_proj = self.online_net(x, groups=2, stage_done=self._grad_stage_cb)
                 online_pred = self.predictor(online_proj, groups=2)
                 with torch.no_grad():
                     self._update_target_net()                      # EMA BEFORE the target forward (:364)

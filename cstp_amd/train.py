@@ -100,6 +100,69 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+class StagedAllReduce:
+    """The gradient all-reduce of DistributedDataParallel (models/model.py:97-103: per-bucket reduction OVERLAPPED with the
+    backward pass) on the flat gradient arena: the arena is reduced in the slices the backward pass completes --
+    [projector | predictor | heads], conv5, conv4, conv3, conv2, stem (ByolBase.grad_stage_slices) -- each started from an
+    autograd hook the moment its gradients are enqueued, on the weight-gradient side stream (which is made to wait for the
+    main stream's gradients of that slice), so the main stream's data-gradient chain never waits for a collective and
+    only the last slice (the stem: 0.04 % of the arena) is reduced after backward has finished.  ``finish()`` reduces
+    whatever has not been started (everything, if no hook fired), waits for all slices and leaves the MEAN over ranks in
+    the arena.  On two ranks the result equals the one-piece reduce bit for bit (a + b in either order); on more ranks a
+    ring's summation order depends on the element's position in the message, as it does between DDP's buckets."""
+
+    def __init__(self, model, flat_grad):
+        inner = model.module if hasattr(model, "module") else model
+        slices = inner.grad_stage_slices() if hasattr(inner, "grad_stage_slices") else None
+        self.flat = flat_grad
+        self.slices = slices or [(0, flat_grad.numel())]
+        self.inner = inner if slices is not None else None
+        self._works, self._next = [], 0
+        if self.inner is not None:
+            self.inner._grad_stage_cb = self.stage_done
+
+    @staticmethod
+    def active() -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin(self):
+        self._works, self._next = [], 0
+
+    def _reduce(self, k):
+        off, n = self.slices[k]
+        t = self.flat[off:off + n]
+        if t.is_cuda:
+            # the slice's gradients were written on the main stream (data-gradient chain, BatchNorm) and on the weight-gradient
+            # side stream: the collective is issued from the side stream once that stream has also seen the main stream's work
+            main = torch.cuda.current_stream(t.device)
+            side = ops._side_stream(t.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+    def stage_done(self, i):
+        """autograd hook: stages 0..i are complete (a later stage's hook may fire first when an earlier one had no hook)."""
+        if not self.active():
+            return
+        while self._next <= i and self._next < len(self.slices) - 1:
+            self._reduce(self._next)
+            self._next += 1
+
+    def finish(self):
+        if not self.active():
+            return self.flat
+        while self._next < len(self.slices):
+            self._reduce(self._next)
+            self._next += 1
+        for w in self._works:
+            w.wait()                      # the current stream waits for the collective
+        self._works = []
+        self.flat.mul_(1.0 / dist.get_world_size())
+        return self.flat
+
+
 def sync_buffers(model) -> bool:
     """Rank 0's BN running statistics / counters -> every rank: what DistributedDataParallel(broadcast_buffers=True), the
     reference's wrap (models/model.py:97-103), does at the start of EVERY forward, train or eval.  The steps below call
@@ -129,19 +192,23 @@ class PretrainStep:
         self._inner = model.module if hasattr(model, "module") else model
         arenas = getattr(self._inner, "_arenas", None)
         self._flat_grad = arenas["grad"] if (flat_allreduce and arenas is not None and hasattr(model, "no_sync")) else None
+        self._reducer = StagedAllReduce(model, self._flat_grad) if self._flat_grad is not None else None
         # weight gradients may bypass autograd's accumulation (side stream, ops._Conv3d.backward) when the gradients live in
-        # the arena and no DDP reducer hook waits for them
-        ops.DIRECT_WGRAD = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
+        # the arena and no DDP reducer hook waits for them: a property of THIS step's model (ops.direct_wgrad_params)
+        self._direct = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
+        ops.mark_direct_grad(self._inner, arenas, self._direct)
         self._tiles_shared = False
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
         if self._flat_grad is not None:
             sync_buffers(self.model)                  # DDP's per-forward buffer broadcast (see the class docstring)
         sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
+        if self._reducer is not None:
+            self._reducer.begin()
         with sync_ctx:
             out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
-        if self._flat_grad is not None:
-            allreduce_mean_(self._flat_grad)
+        if self._reducer is not None:
+            self._reducer.finish()
         gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None
         self.optimizer.step()
         out.grad_norm = gnorm
@@ -149,7 +216,7 @@ class PretrainStep:
             # every layer geometry has been seen (and tuned, if the persisted table lacked it) once: all ranks adopt rank
             # 0's tiles so that the same layer runs the same kernel everywhere
             self._tiles_shared = True
-            if self._flat_grad is not None and self._flat_grad.is_cuda:
+            if self._flat_grad is None or self._flat_grad.is_cuda:
                 ops.share_tune_table()
         return out
 
@@ -192,7 +259,8 @@ class FineTuneStep:
         arenas = getattr(inner, "_arenas", None)
         self._flat = flat_allreduce and arenas is not None and hasattr(model, "no_sync") and hasattr(optimizer, "_plan")
         self._g = arenas["grad"] if arenas is not None else None
-        ops.DIRECT_WGRAD = arenas is not None and (self._flat or not hasattr(model, "no_sync"))
+        ops.mark_direct_grad(inner, arenas, arenas is not None and (self._flat or not hasattr(model, "no_sync")))
+        self._tiles_shared = False
 
     def __call__(self, inputs, targets):
         if self._flat:
@@ -207,4 +275,8 @@ class FineTuneStep:
             for off, n, _, _ in self.optimizer._plan():
                 allreduce_mean_(self._g[off:off + n])
         self.optimizer.step()
+        if not self._tiles_shared:            # all ranks adopt rank 0's tuned tiles (see PretrainStep)
+            self._tiles_shared = True
+            if self._flat and self._g is not None and self._g.is_cuda:
+                ops.share_tune_table()
         return loss.detach(), outputs.detach()

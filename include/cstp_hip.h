@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 14
+#define CSTP_ABI_VERSION 15
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -84,11 +84,14 @@ int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float
  * per-channel, per-group sums of y and y^2 as fp64 partials part[k][groups][nsplit][2] (cstp_bn_forward_train_pre folds
  * them: the BatchNorm then needs no statistics pass over y).  *nsplit = partials per (channel, group), or 0 when this layer's
  * kernel cannot deliver them -- the call is then exactly cstp_conv3d_forward_am and BatchNorm takes its usual path.
- * cstp_conv3d_bnstats_nsplit: the same answer in advance (part needs k * groups * nsplit * 2 doubles). */
+ * cstp_conv3d_bnstats_nsplit: the same answer in advance (part needs k * groups * nsplit * 2 + k doubles).
+ * pivot (float[k] on the device, or NULL = zeros): the sums are taken AROUND it -- sum(y - pivot[ch]), sum((y - pivot[ch])^2) --
+ * and the launch stores the values it used in the last k doubles of part; any finite values are correct, values near the
+ * channel means (the BatchNorm's running_mean) keep the variance free of cancellation when |mean| >> std. */
 int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups);
 int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y, void* ws,
-                                size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, double* part, size_t part_bytes,
-                                int32_t* nsplit);
+                                size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot, double* part,
+                                size_t part_bytes, int32_t* nsplit);
 int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
                                  void* ws, size_t ws_bytes, const uint32_t* dy_absmax);
 int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x, const cstp_in_affine* in_affine,
@@ -170,7 +173,8 @@ int cstp_bn_forward_train_am(void* stream, const float* x, const float* residual
                              float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
                              float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax);
 /* ... with the statistics pass replaced by the partial sums a producing convolution left (cstp_conv3d_forward_bnstats;
- * part[c][groups][nsplit][2] fp64 sums of x and x^2; s > 1).  Everything else as cstp_bn_forward_train_am. */
+ * part[c][groups][nsplit][2] fp64 sums of (x - pivot) and (x - pivot)^2, then pivot[c]; s > 1).  Everything else as
+ * cstp_bn_forward_train_am. */
 int cstp_bn_forward_train_pre(void* stream, const float* x, const float* residual, float* y, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float* save_mean,
                               float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,

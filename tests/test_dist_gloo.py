@@ -169,10 +169,21 @@ def _make_stub(dtype=torch.float64):
             self.register_buffer("running", self._arenas["buffers"])
             self.entry_log = []
 
+        _grad_stage_cb = None          # installed by the step's StagedAllReduce, as on ByolBase
+
+        def grad_stage_slices(self):
+            """two gradient stages in backward-completion order: the heads (behind the encoder in the arena), then the encoder"""
+            n_enc = self.enc.weight.numel()
+            return [(n_enc, self._arenas["grad"].numel() - n_enc), (0, n_enc)]
+
         def forward(self, x1, x2, o_type=None):
             assert o_type == "loss_com"
             self.entry_log.append(self._arenas["buffers"].clone())      # what this rank's forward STARTS from
-            f1, f2 = self.enc(x1), self.enc(x2)
+            f = self.enc(torch.cat((x1, x2)))
+            if self._grad_stage_cb is not None and f.requires_grad:
+                f.register_hook(lambda g: self._grad_stage_cb(0))        # the heads' gradients are complete
+                self.hooked = getattr(self, "hooked", 0) + 1
+            f1, f2 = f[:x1.shape[0]], f[x1.shape[0]:]
             with torch.no_grad():                                        # per-rank statistics, as train-mode BN
                 self._arenas["buffers"].mul_(0.9).add_(0.1 * f1.mean(0).float())
                 self._arenas["nbt_all"] += 1
@@ -206,6 +217,7 @@ def _worker_pretrain_step(rank, port, q):
     ntx = NTXentLoss(device="cpu", batch_size=8, temperature=0.5, kernel=kern)
     step = PretrainStep(ddp, opt, w, clip_grad_norm=True, ntxent=ntx, ntxent_weight=ntw, cross_entropy=F.cross_entropy)
     assert step._flat_grad is model._arenas["grad"]
+    assert step._reducer is not None and len(step._reducer.slices) == 2 and model._grad_stage_cb is not None
     x1, x2, lab = _stub_data()
     sl = slice(4 * rank, 4 * rank + 4)
     outs = []
@@ -245,6 +257,48 @@ def test_ntxent_all_gather_gradient_and_ddp_scale():
         assert abs(loss - ref) < 1e-12          # every rank evaluates the same global loss
         assert err_full < 1e-12                 # DDP's mean over ranks of grad(world * loss) == global-batch gradient
         assert err_local < 1e-12
+
+
+def _worker_staged_allreduce(rank, port, q):
+    """The slice-wise reduce started from backward hooks (train.StagedAllReduce) against the one-piece reduce."""
+    from cstp_amd.train import StagedAllReduce, allreduce_mean_
+    _init(rank, port)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(1003, generator=g, dtype=torch.float32) * (10.0 ** torch.randint(-3, 4, (1003,), generator=g))
+    ref = allreduce_mean_(flat.clone())
+
+    class M:
+        _grad_stage_cb = None
+
+        def grad_stage_slices(self):
+            return [(700, 303), (400, 300), (16, 384), (0, 16)]          # completion order; together they tile the arena
+    m = M()
+    red = StagedAllReduce(m, flat)
+    assert m._grad_stage_cb is not None and len(red.slices) == 4
+    red.begin()
+    m._grad_stage_cb(0)
+    assert red._next == 1
+    m._grad_stage_cb(2)                    # stage 1 had no hook of its own: reduced together with stage 2
+    assert red._next == 3 and len(red._works) == 3
+    out = red.finish()                     # the last slice + wait + mean
+    same = bool(torch.equal(out, ref))
+    # no hook at all (a model without stage marks): finish() reduces everything
+    flat2 = torch.randn(1003, generator=torch.Generator().manual_seed(100 + rank), dtype=torch.float32)
+    ref2 = allreduce_mean_(flat2.clone())
+    red2 = StagedAllReduce(object(), flat2)
+    red2.begin()
+    same2 = bool(torch.equal(red2.finish(), ref2)) and len(red2.slices) == 1
+    q.put((rank, same, same2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_staged_gradient_allreduce_equals_the_flat_one_bit_for_bit():
+    """models/model.py:97-103 overlaps the gradient reduction with backward (DDP buckets); the flat-arena equivalent reduces
+    the arena in backward-completion slices from autograd hooks.  On two ranks the result must be bit-identical to the
+    one-piece reduce."""
+    for rank, same, same2 in _run(_worker_staged_allreduce, WORLD):
+        assert same and same2
 
 
 def test_flat_gradient_allreduce_is_the_mean_over_ranks():

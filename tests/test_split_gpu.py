@@ -391,6 +391,55 @@ def test_patch_kernel_leaves_batchnorm_statistics(name, groups):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2])
+def test_patch_kernel_batchnorm_statistics_of_channels_whose_mean_is_far_above_their_spread(groups):
+    """Round-2 ADVICE: the fused sums are fp32 per lane before they reach fp64, and var = E[y^2] - mean^2 cancels when
+    |mean| >> std.  Channels here sit at |mean| / std ~ 1e2 (mean 14, std 0.12).  With the BatchNorm's running mean as the
+    PIVOT the sums are taken around (cstp_conv3d_forward_bnstats: sum(y - c), sum((y - c)^2)) the fused path holds the
+    same 1e-4 bar against fp64 as the separate fp64-accumulating pass -- also with a pivot that is 3 std off, and the
+    running statistics come out right."""
+    from cstp_amd import ops
+    xs, k, mt = BNSTAT_GEOMS["one row block"]
+    ws = (k, xs[1], 1, 3, 3)
+    ops.set_split_terms(2)
+    ops.set_conv_tile(xs, ws, (1, 1, 1), (0, 1, 1), 0, (2, mt, 0, 0))
+    try:
+        g = torch.Generator().manual_seed(9)
+        x = (1.0 + 0.1 * torch.randn(xs, generator=g)).cuda()
+        w = (0.05 + 0.1 * torch.rand(ws, generator=g)).cuda()
+        gamma, beta = (torch.rand(k, generator=g) + 0.5).cuda(), torch.randn(k, generator=g).cuda()
+        yc = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (0, 1, 1))
+        mean, std = yc.mean(dim=(0, 2, 3, 4)), yc.std(dim=(0, 2, 3, 4))
+        assert float((mean.abs() / std).min()) > 50
+        pivot0 = (mean + 3 * std).float()               # a running mean that is off by three standard deviations
+
+        def truth():
+            outs, rm, rv = [], pivot0.double().clone(), torch.ones(k, dtype=torch.float64)
+            for part in yc.chunk(groups, 0):
+                outs.append(F.relu(F.batch_norm(part, rm, rv, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)))
+            return torch.cat(outs, 0), rm, rv
+
+        def run(fused, pivot):
+            rm, rv = pivot0.cuda().clone(), torch.ones(k, device="cuda")
+            y = ops.conv3d(x, w, None, 1, (0, 1, 1), bn_groups=groups if fused else 0, bn_pivot=rm if pivot else None)
+            assert (getattr(y, "_cstp_bnstats", None) is not None) == fused
+            return ops.batch_norm_act(y, gamma, beta, rm, rv, None, True, 1e-5, 0.1, groups), rm, rv
+
+        ref, rm64, rv64 = truth()
+        sep, _, _ = run(False, False)
+        piv, rmp, rvp = run(True, True)
+        nop, _, _ = run(True, False)
+        e_sep, e_piv, e_nop = rel_err(sep.cpu().double(), ref), rel_err(piv.cpu().double(), ref), rel_err(nop.cpu().double(), ref)
+        print("BN output vs fp64 at |mean|/std ~ %.0f: separate pass %.2e, fused around the pivot %.2e, fused around zero %.2e"
+              % (float((mean.abs() / std).mean()), e_sep, e_piv, e_nop))
+        assert e_sep < 1e-4 and e_piv < 1e-4
+        assert e_piv < 2 * e_sep + 2e-6                  # the fusion costs no accuracy
+        assert rel_err(rmp.cpu().double(), rm64) < 1e-6 and rel_err(rvp.cpu().double(), rv64) < 1e-4
+    finally:
+        ops.set_split_terms(0)
+
+
+@pytest.mark.gpu
 def test_batchnorm_statistics_by_product_is_declined_where_it_cannot_be_exact():
     """Tiles that straddle two BN groups, a gather-kernel tile, or frames that rule out 16-byte stores: nsplit = 0 and the
     call is the plain forward (BatchNorm then makes its own pass)."""
