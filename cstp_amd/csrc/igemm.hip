@@ -747,14 +747,14 @@ static bool patch_geom_ok(const cstp_conv_desc& d) {
   if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
   return patch_rows_needed(d.n * d.d, d.h, d.w) <= KP_ROWS;
 }
-// the weight-gradient patch kernel igemm_k2p (igemm_wpatch.h): the same layers; its x ring holds 2 * (W + 2) + 34 rows <= 7 segments
+// the weight-gradient patch kernel igemm_k2p (igemm_wpatch.h): the same layers; its x staging leads by <= 5 intervals of 64 rows
 static bool wpatch_geom_ok(const cstp_conv_desc& d) {
   if (!(d.kt == 1 && d.kh == 3 && d.kw == 3 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 1 && d.pw == 1))
     return false;
   if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
   // (stream rows and frame counts stay below 2^25 and the divisors below 129: the kernel divides by multiplication)
   if ((long)d.n * d.d * (d.h + 1) * (d.w + 2) >= (1l << 25) || d.h + 1 > 128 || d.d > 128) return false;
-  return 2 * (d.w + 2) + 34 <= 7 * 32;
+  return 2 * (d.w + 2) + 66 <= 5 * 64;
 }
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
@@ -1187,7 +1187,7 @@ static int run_k2p(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, co
   g.C = d.c; g.M = d.k;
   g.ncb = cdiv(d.c, 32); g.nmblk = cdiv(d.k, WP_BM);
   g.H = d.h; g.W = d.w; g.D = d.d; g.NF = d.n * d.d;
-  g.lead = cdiv(2 * (d.w + 2) + 34, 32);
+  g.lead = cdiv(2 * (d.w + 2) + 66, 64);
   g.Jp = p.w_Jp; g.Cp = p.w_Cp;
   g.mg_pitch = (unsigned)((1ull << 32) / (unsigned)(d.w + 2) + 1);
   g.mg_hp1 = (unsigned)((1ull << 32) / (unsigned)(d.h + 1) + 1);
