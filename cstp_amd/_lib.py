@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_uint32, POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
@@ -93,6 +93,14 @@ SIGNATURES = {
     "cstp_ntxent_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, c_size_t]),
     "cstp_clip_assemble": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                      c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "cstp_clip_assemble_u8": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                        c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "cstp_clip_rotate": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "cstp_clip_blend": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, _P]),
+    "cstp_clip_hue": (c_int32, [_P, _P, _P, c_size_t, c_int32, c_int32]),
+    "cstp_clip_gray": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "cstp_clip_box_blur": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_uint32, c_uint32, c_int32]),
+    "cstp_clip_finish": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32]),
     "cstp_ema_update": (c_int32, [_P, _P, _P, c_size_t, c_double]),
     "cstp_sumsq": (c_int32, [_P, _P, c_size_t, _P, _P, c_size_t]),
     "cstp_clip_coef": (c_int32, [_P, _P, c_float, _P, _P]),

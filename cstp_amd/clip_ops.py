@@ -3,7 +3,8 @@ the launch, and a clip-pair builder / dataset that turns decoded uint8 videos re
 sample ``([clip_1, clip_2], [spa_label, tem_label, pb_label, [rot_label_1, rot_label_2]])`` (datasets.py:855-857) with the
 decisions of cstp_amd.sampler.
 
-Replaces, for the `null_transform` path, the reference's per-worker PIL pipeline (Image.open -> transpose -> crop -> resize ->
+Replaces the reference's per-worker PIL pipeline, both its `null_transform` path and its `base_transform` path (small-angle
+rotation, colour jitter, channel gray, Gaussian blur on the resized 8-bit frames: preprocess_data.py:1110-1121) -- (Image.open -> transpose -> crop -> resize ->
 flip -> ToTensor -> normalise on the CPU, 6 DataLoader workers per GPU, preprocess_data.py:1103-1130): the frames are uploaded
 once as uint8 and every clip is produced where it is consumed.  There is no CPU implementation here.
 """
@@ -76,8 +77,136 @@ def _device_tables(in_size: int, out_size: int, device: torch.device):
     return t
 
 
+# ---- the base_transform branch: host-side constants of the Pillow algorithms the kernels reproduce --------------------------
+def rotate_coeffs(w: int, h: int, angle: float):
+    """Image.rotate(angle)'s reverse affine matrix about (w / 2, h / 2) (PIL/Image.py) as Geometry.c affine_fixed's six 16.16
+    fixed-point coefficients; None for the angles Image.rotate serves by a transpose or a copy."""
+    a = angle % 360.0
+    if a == 0 or a == 180 or (a in (90, 270) and w == h):
+        return None
+    r = -math.radians(a)
+    m = [round(math.cos(r), 15), round(math.sin(r), 15), 0.0, round(-math.sin(r), 15), round(math.cos(r), 15), 0.0]
+    cx, cy = w / 2, h / 2
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2] + cx
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5] + cy
+
+    def fix(v):
+        return int(math.floor(v * 65536.0 + 0.5))
+    return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
+
+
+def gaussian_box_weights(sigma: float, passes: int = 3):
+    """ImageFilter.GaussianBlur(sigma) -> (integer box radius, ww, fw) of BoxBlur.c: _gaussian_blur_radius in its float / double
+    mix, then the two 24-bit fixed-point weights of ImagingLineBoxBlur8 (a float division)."""
+    f32, f64 = np.float32, np.float64
+    sigma2 = f32(f32(sigma) * f32(sigma) / f32(passes))
+    big_l = f32(math.sqrt(12.0 * f64(sigma2) + 1.0))
+    small_l = f32(math.floor((f64(big_l) - 1.0) / 2.0))
+    a = f32(f64(f32(2) * small_l + f32(1)) * (f64(small_l * (small_l + f32(1))) - 3.0 * f64(sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - (small_l + f32(1)) * (small_l + f32(1)))))
+    radius = f32(small_l + a)
+    r_int = int(radius)
+    ww = int(f32(1 << 24) / f32(radius * f32(2) + f32(1)))
+    fw = ((1 << 24) - (r_int * 2 + 1) * ww) // 2
+    return r_int, ww, fw
+
+
+def _u8_clip(t):
+    if not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3:
+        raise _lib.CstpError("expected a uint8 [T, H, W, 3] clip on a HIP device (cstp_amd has no CPU path)")
+    return t.contiguous()
+
+
+def clip_rotate(clip: torch.Tensor, angle: float) -> torch.Tensor:
+    """Every frame of the clip through Image.rotate(angle) (RandomRotation, preprocess_data.py:1091-1094)."""
+    clip = _u8_clip(clip)
+    t, h, w, _ = clip.shape
+    a = angle % 360.0
+    coef = rotate_coeffs(w, h, angle)
+    if coef is None:      # Image.rotate's fast paths: copy / transpose
+        return clip.clone() if a == 0 else torch.rot90(clip, {90: 1, 180: 2, 270: 3}[int(a)], dims=(1, 2)).contiguous()
+    out = torch.empty_like(clip)
+    check(_lib.load().cstp_clip_rotate(torch.cuda.current_stream().cuda_stream, clip.data_ptr(), out.data_ptr(), t, h, w,
+                                       (ctypes.c_int32 * 6)(*coef)), "cstp_clip_rotate")
+    return out
+
+
+_BLEND_MODE = {"brightness": 0, "contrast": 1, "saturation": 2}
+
+
+def clip_colour(clip: torch.Tensor, op: str, factor: float) -> torch.Tensor:
+    """torchvision adjust_brightness / adjust_contrast / adjust_saturation / adjust_hue on every frame (ClipColorJitter)."""
+    clip = _u8_clip(clip)
+    t, h, w, _ = clip.shape
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    out = torch.empty_like(clip)
+    if op == "hue":
+        if not -0.5 <= factor <= 0.5:
+            raise ValueError("hue_factor is not in [-0.5, 0.5]")
+        shift = int(np.array(factor * 255).astype(np.uint8))
+        check(lib.cstp_clip_hue(st, clip.data_ptr(), out.data_ptr(), t * h * w, shift, 0), "cstp_clip_hue")
+        return out
+    if op not in _BLEND_MODE:
+        raise ValueError("colour operation %r" % (op,))
+    if factor == 1.0:      # Image.blend returns a copy of the image
+        return clip.clone()
+    means = torch.empty(t, dtype=torch.int32, device=clip.device) if op == "contrast" else None
+    check(lib.cstp_clip_blend(st, clip.data_ptr(), out.data_ptr(), t, h, w, _BLEND_MODE[op], float(factor),
+                              None if means is None else means.data_ptr()), "cstp_clip_blend")
+    return out
+
+
+def clip_gray(clip: torch.Tensor, channels) -> torch.Tensor:
+    """ClipRandomGray.grayscale: frame i keeps channels[i] in all three channels."""
+    clip = _u8_clip(clip)
+    t, h, w, _ = clip.shape
+    if len(channels) != t:
+        raise ValueError("%d channel choices for %d frames" % (len(channels), t))
+    ch = torch.tensor([int(c) for c in channels], dtype=torch.int32, device=clip.device)
+    out = torch.empty_like(clip)
+    check(_lib.load().cstp_clip_gray(torch.cuda.current_stream().cuda_stream, clip.data_ptr(), out.data_ptr(), t, h, w,
+                                     ch.data_ptr()), "cstp_clip_gray")
+    return out
+
+
+def clip_gaussian_blur(clip: torch.Tensor, sigma: float) -> torch.Tensor:
+    """Every frame through ImageFilter.GaussianBlur(radius=sigma) (ClipGaussianBlur)."""
+    clip = _u8_clip(clip)
+    if sigma == 0:
+        return clip.clone()
+    t, h, w, _ = clip.shape
+    r_int, ww, fw = gaussian_box_weights(sigma)
+    out, tmp = clip.clone(), torch.empty_like(clip)
+    check(_lib.load().cstp_clip_box_blur(torch.cuda.current_stream().cuda_stream, out.data_ptr(), tmp.data_ptr(), t, h, w, r_int,
+                                         ww, fw, 3), "cstp_clip_box_blur")
+    return out
+
+
+def clip_finish(clip: torch.Tensor, flip: bool) -> torch.Tensor:
+    """[flip] -> ToTensor -> 'tf' normalise: uint8 [T][S][S][3] -> fp32 [3][T][S][S]."""
+    clip = _u8_clip(clip)
+    t, h, w, _ = clip.shape
+    out = torch.empty((3, t, h, w), dtype=torch.float32, device=clip.device)
+    check(_lib.load().cstp_clip_finish(torch.cuda.current_stream().cuda_stream, clip.data_ptr(), out.data_ptr(), t, h, w,
+                                       1 if flip else 0), "cstp_clip_finish")
+    return out
+
+
+def apply_base_transform(clip: torch.Tensor, base: "sampler.BasePlan", flip: bool) -> torch.Tensor:
+    """base_transform (preprocess_data.py:1110-1121) on the resized 8-bit clip, in Compose order."""
+    clip = clip_rotate(clip, base.angle)
+    for op, factor in (base.jitter or ()):
+        clip = clip_colour(clip, op, factor)
+    if base.gray is not None:
+        clip = clip_gray(clip, base.gray)
+    if base.blur_sigma is not None:
+        clip = clip_gaussian_blur(clip, base.blur_sigma)
+    return clip_finish(clip, flip)
+
+
 def assemble_clip(frames: torch.Tensor, plan: "sampler.ClipPlan", size: int) -> torch.Tensor:
-    """frames: uint8 [F][H][W][3] on a HIP device -> fp32 [3][T][size][size] (torch.stack(clip).transpose(0, 1))."""
+    """frames: uint8 [F][H][W][3] on a HIP device -> fp32 [3][T][size][size] (torch.stack(clip).transpose(0, 1)).
+    A plan that carries base_transform draws (plan.base) is resized to 8-bit frames first and taken through that branch."""
     lib = _lib.load()
     if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
         raise _lib.CstpError("frames must be a uint8 [F, H, W, 3] tensor on a HIP device (cstp_amd has no CPU path)")
@@ -92,6 +221,13 @@ def assemble_clip(frames: torch.Tensor, plan: "sampler.ClipPlan", size: int) -> 
     t = len(plan.frames)
     idx = torch.tensor(plan.frames, dtype=torch.int32, device=dev)
     tmp = torch.empty((t, last - first, size, 3), dtype=torch.uint8, device=dev)
+    if getattr(plan, "base", None) is not None:
+        u8 = torch.empty((t, size, size, 3), dtype=torch.uint8, device=dev)
+        check(lib.cstp_clip_assemble_u8(torch.cuda.current_stream().cuda_stream, frames.data_ptr(), f, h, w, idx.data_ptr(), t,
+                                        int(plan.rotate), int(x0), int(y0), int(size), kh.data_ptr(), bh.data_ptr(), ksh,
+                                        kv.data_ptr(), bv.data_ptr(), ksv, first, last - first, tmp.data_ptr(), u8.data_ptr()),
+              "cstp_clip_assemble_u8")
+        return apply_base_transform(u8, plan.base, plan.flip)
     out = torch.empty((3, t, size, size), dtype=torch.float32, device=dev)
     check(lib.cstp_clip_assemble(torch.cuda.current_stream().cuda_stream, frames.data_ptr(), f, h, w, idx.data_ptr(), t,
                                  int(plan.rotate), int(x0), int(y0), int(size), 1 if plan.flip else 0, kh.data_ptr(), bh.data_ptr(),
@@ -131,9 +267,10 @@ class GpuVideoClips:
 
     def sample(self, index: int):
         rng = random.Random(self.seed * 1000003 + index)
+        np_rng = np.random.RandomState((self.seed * 1000003 + index) & 0x7fffffff)      # ClipRandomGray's np.random.choice
         video = self.videos[index % len(self.videos)]
         f, h, w, _ = video.shape
-        return assemble_pair(video, sampler.sample_pair(f, w, h, self.t, rng), self.size)
+        return assemble_pair(video, sampler.sample_pair(f, w, h, self.t, rng, np_rng=np_rng), self.size)
 
     def batch(self, indices: List[int]):
         """-> (clip_1 [B,3,T,S,S], clip_2, spa, tem, pb, rot_1, rot_2) on the device, labels int64."""

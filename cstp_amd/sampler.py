@@ -9,18 +9,22 @@ What a plan says and what executes it: frame indices, 90-degree rotation codes, 
 decided here on the host (a few dozen integers per pair); the pixels never touch the host -- ``cstp_amd.clip_ops.assemble_pair``
 runs rotate -> crop -> bicubic resize -> flip -> tensor -> 'tf' normalise on the decoded uint8 frames resident in HBM.
 
-Scope note: the reference applies its ``base_transform`` (small-angle rotation, colour jitter, channel-split "gray", Gaussian
-blur; preprocess_data.py:1110-1121, torchvision + cv2 code that cannot be imported here) to a clip with probability 0.3 and
-the ``null_transform`` (flip, tensor, normalise) otherwise.  The plan records that choice (``use_base``); the executor implements
-the null path, which is also what a clip with ``use_base`` gets here.  The reference bug that reads clip 2 of the LMDB dataset
-from ``start_frame`` instead of ``start_frame_2`` (datasets.py:1397) is not replicated.
+The reference applies its ``base_transform`` (preprocess_data.py:1110-1121: RandomRotation(10), ClipColorJitter(0.4, 0.4, 0.4,
+0.1) with p = 0.8, ClipRandomGray(p = 0.2), ClipGaussianBlur([0.1, 2]) with p = 0.5, then flip / tensor / normalise) to a clip
+with probability 0.3 and the ``null_transform`` (flip, tensor, normalise) otherwise (TwoClipTransform :713-741).  The plan
+records that choice and, for a base clip, every parameter the branch draws (``BasePlan``), in the reference's draw order --
+``transforms.RandomApply`` as the torchvision of the reference's era implements it (``if self.p < random.random(): skip``;
+current torchvision draws from torch's generator instead), ``random.shuffle`` of the four colour operations, the channel of
+ClipRandomGray per frame from a NumPy ``RandomState`` (the reference calls ``np.random.choice(3)``).  The executor
+(cstp_amd.clip_ops) runs both branches on the GPU.  The reference bug that reads clip 2 of the LMDB dataset from
+``start_frame`` instead of ``start_frame_2`` (datasets.py:1397) is not replicated.
 """
 from __future__ import annotations
 
 import math
 import random
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 PACE = [1, 2, 4, 8]                               # datasets.py:17
 OVERLAP_TEM_RATE = [1.0, 0.8, 0.6, 0.4, 0.2]      # datasets.py:18
@@ -29,12 +33,23 @@ OVERLAP_SPA_RATE = [1.0, 0.8, 0.6, 0.4, 0.2]      # preprocess_data.py:18
 
 
 @dataclass
+class BasePlan:
+    """The draws of one pass through base_transform (preprocess_data.py:1110-1121), applied to the resized 8-bit frames."""
+    angle: float                               # RandomRotation(10): Image.rotate(angle)
+    jitter: Optional[List[Tuple[str, float]]]  # ClipColorJitter: ("brightness" | "contrast" | "saturation" | "hue", factor) in
+                                               #   the shuffled order, or None (RandomApply p = 0.8 skipped it)
+    gray: Optional[List[int]]                  # ClipRandomGray: the channel kept per frame, or None
+    blur_sigma: Optional[float]                # ClipGaussianBlur: one sigma per clip, or None (RandomApply p = 0.5)
+
+
+@dataclass
 class ClipPlan:
     frames: List[int]            # 0-based frame indices, in clip order
     rotate: int                  # 0 / 90 / 180 / 270, applied to the whole frame before cropping
     box: Tuple[int, int, int, int]   # (x0, y0, x1, y1) in the ROTATED frame
     flip: bool
-    use_base: bool               # the reference would run its base_transform on this clip (see module docstring)
+    use_base: bool               # TwoClipTransform chose base_transform for this clip (p = 0.3)
+    base: Optional[BasePlan] = None   # its draws (None: null_transform)
 
 
 @dataclass
@@ -145,11 +160,34 @@ def _rotated_size(w: int, h: int, rot: int) -> Tuple[int, int]:
     return (h, w) if rot in (90, 270) else (w, h)
 
 
+def base_draws(rng: random.Random, np_rng, n_frames: int, sample_duration: int) -> BasePlan:
+    """base_transform's random draws up to (not including) the flip, in Compose order (preprocess_data.py:1110-1119)."""
+    angle = rng.uniform(-10, 10)                               # RandomRotation(10) :1091
+    jitter = None
+    if not 0.8 < rng.random():                                 # transforms.RandomApply(p = 0.8)
+        rng.random()                                           # ClipColorJitter.__call__: random.random() < p (= 1.0) :658
+        ops = [("brightness", rng.uniform(0.6, 1.4)), ("contrast", rng.uniform(0.6, 1.4)),
+               ("saturation", rng.uniform(0.6, 1.4)), ("hue", rng.uniform(-0.1, 0.1))]       # get_params :632-648
+        rng.shuffle(ops)                                       # random.shuffle(transforms) :650
+        jitter = ops
+    gray = None
+    if rng.random() < 0.2:                                     # ClipRandomGray(p = 0.2) :699
+        if np_rng is None:
+            raise ValueError("the ClipRandomGray channel draws need a numpy RandomState (np.random.choice(3), :705)")
+        gray = [int(np_rng.choice(3)) for _ in range(n_frames)]
+    sigma = None
+    if not 0.5 < rng.random():                                 # transforms.RandomApply(p = 0.5)
+        for idx in range(n_frames):                            # ClipGaussianBlur :682-686: a new sigma every sample_duration frames
+            if idx % sample_duration == 0:
+                sigma = rng.uniform(0.1, 2.0)
+    return BasePlan(angle, jitter, gray, sigma)
+
+
 def sample_pair(total_frames: int, frame_w: int, frame_h: int, sample_duration: int, rng: random.Random,
-                p_base: float = 0.3) -> PairPlan:
+                p_base: float = 0.3, np_rng=None) -> PairPlan:
     """One training sample of the 'pre_train' pipeline: repre_train_clip (frames, rotations, temporal / playback labels), then
     TwoClipTransform (preprocess_data.py:713-741): base-or-null draw for each clip, overlap crop of clip 1, its flip, overlap
-    crop of clip 2, its flip.  Both clips of a pair are cropped in the coordinates of THEIR OWN rotated frames; the reference
+    crop of clip 2, its flip -- with the base_transform draws of a clip (``base_draws``) between its crop and its flip.  Both clips of a pair are cropped in the coordinates of THEIR OWN rotated frames; the reference
     takes the image size from the first frame of each clip list, which is what this does."""
     idx_1, idx_2, tem_label, pb_label, (r1, r2) = sample_frames(total_frames, sample_duration, rng)
     rng.choices(range(2), weights=[1, 0])                     # TransformController picks TwoClipTransform (:779, weights [1, 0])
@@ -158,9 +196,11 @@ def sample_pair(total_frames: int, frame_w: int, frame_h: int, sample_duration: 
     crop = OverlapCrop(rng)
     w1, h1 = _rotated_size(frame_w, frame_h, ROTATE[r1])
     box_1 = crop.first(w1, h1)
+    base_1 = base_draws(rng, np_rng, len(idx_1), sample_duration) if use_base_1 else None     # q = tr1(q) :736
     flip_1 = rng.random() < 0.5
     w2, h2 = _rotated_size(frame_w, frame_h, ROTATE[r2])
     box_2, spa_label = crop.second(w2, h2)
+    base_2 = base_draws(rng, np_rng, len(idx_2), sample_duration) if use_base_2 else None     # k = tr2(k) :738
     flip_2 = rng.random() < 0.5
-    return PairPlan(ClipPlan(idx_1, ROTATE[r1], box_1, flip_1, use_base_1), ClipPlan(idx_2, ROTATE[r2], box_2, flip_2, use_base_2),
-                    spa_label, tem_label, pb_label, (r1, r2))
+    return PairPlan(ClipPlan(idx_1, ROTATE[r1], box_1, flip_1, use_base_1, base_1),
+                    ClipPlan(idx_2, ROTATE[r2], box_2, flip_2, use_base_2, base_2), spa_label, tem_label, pb_label, (r1, r2))

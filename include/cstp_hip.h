@@ -268,6 +268,35 @@ int cstp_clip_assemble(void* stream, const uint8_t* frames, int32_t f, int32_t h
                        const int32_t* bh, int32_t ksh, const int32_t* kv, const int32_t* bv, int32_t ksv, int32_t row_first,
                        int32_t rows, uint8_t* tmp, float* out);
 
+/* ... the same up to the resize, result kept as 8-bit RGB [t][size][size][3] (no flip, no normalisation): the input of the
+ * base_transform operations below. */
+int cstp_clip_assemble_u8(void* stream, const uint8_t* frames, int32_t f, int32_t h, int32_t w, const int32_t* frame_idx,
+                          int32_t t, int32_t rot, int32_t box_x0, int32_t box_y0, int32_t size, const int32_t* kh,
+                          const int32_t* bh, int32_t ksh, const int32_t* kv, const int32_t* bv, int32_t ksv, int32_t row_first,
+                          int32_t rows, uint8_t* tmp, uint8_t* out);
+/* ---- the `base_transform` branch of the clip pipeline (data_process/preprocess_data.py:1110-1121; taken with p = 0.3 per clip,
+ * TwoClipTransform :713-741) on 8-bit RGB clips [t][h][w][3] in HBM.  Each entry reproduces, bit for bit, the Pillow call the
+ * reference makes (directly, or through torchvision's PIL backend):
+ *   cstp_clip_rotate    RandomRotation(10) :1060-1100 -> Image.rotate(angle): NEAREST, same size, black fill.  coef6 (HOST
+ *                       pointer) = Geometry.c affine_fixed's six 16.16 fixed-point coefficients of Image.rotate's reverse matrix.
+ *   cstp_clip_blend     ClipColorJitter :584-672 -> adjust_brightness (mode 0), adjust_contrast (1; ws_means: t int32 on the
+ *                       device), adjust_saturation (2) = ImageEnhance.{Brightness, Contrast, Color}.enhance(alpha) = Image.blend.
+ *   cstp_clip_hue       adjust_hue: RGB -> HSV, h += shift (= uint8(hue_factor * 255)) modulo 256, HSV -> RGB; mode 1 / 2: the
+ *                       RGB -> HSV / HSV -> RGB conversion alone.  In place allowed.
+ *   cstp_clip_gray      ClipRandomGray.grayscale :704-709: frame i keeps channel[i] (device int32, < 0 = unchanged) in all three.
+ *   cstp_clip_box_blur  ClipGaussianBlur :675-687 -> ImageFilter.GaussianBlur(radius) = `passes` (3) extended box blurs per axis
+ *                       (BoxBlur.c); radius / ww / fw = integer box radius and its two 24-bit fixed-point weights, computed by
+ *                       the caller as BoxBlur.c does from the float box radius.  In place (tmp: same size scratch).
+ *   cstp_clip_finish    [FLIP_LEFT_RIGHT] -> ToTensor -> x * 2 - 1 clamped: uint8 [t][h][w][3] -> fp32 [3][t][h][w]. */
+int cstp_clip_rotate(void* stream, const uint8_t* src, uint8_t* dst, int32_t t, int32_t h, int32_t w, const int32_t* coef6);
+int cstp_clip_blend(void* stream, const uint8_t* src, uint8_t* dst, int32_t t, int32_t h, int32_t w, int32_t mode, float alpha,
+                    int32_t* ws_means);
+int cstp_clip_hue(void* stream, const uint8_t* src, uint8_t* dst, size_t npix, int32_t shift, int32_t mode);
+int cstp_clip_gray(void* stream, const uint8_t* src, uint8_t* dst, int32_t t, int32_t h, int32_t w, const int32_t* channel);
+int cstp_clip_box_blur(void* stream, uint8_t* img, uint8_t* tmp, int32_t t, int32_t h, int32_t w, int32_t radius, uint32_t ww,
+                       uint32_t fw, int32_t passes);
+int cstp_clip_finish(void* stream, const uint8_t* src, float* out, int32_t t, int32_t h, int32_t w, int32_t flip);
+
 /* ---- per-step utilities over FLAT parameter arenas -------------------------------------- */
 /* EMA r21d_byol.py:331-337: target = target*m + online*(1-m) over n floats. */
 int cstp_ema_update(void* stream, float* target, const float* online, size_t n, double m);

@@ -63,10 +63,15 @@ def test_sampled_pairs_match_the_oracle_and_feed_the_model():
     frames = _frames(70, 96, 128, seed=3)
     dev = torch.from_numpy(frames).cuda()
     for seed in range(12):
-        plan = sampler.sample_pair(70, 128, 96, 16, random.Random(seed))
+        plan = sampler.sample_pair(70, 128, 96, 16, random.Random(seed), np_rng=np.random.RandomState(seed))
         (c1, c2), labels = clip_ops.assemble_pair(dev, plan, 64)
         for c, p in ((c1, plan.clip_1), (c2, plan.clip_2)):
-            assert np.array_equal(c.cpu().numpy(), po.assemble_clip(frames, p.frames, p.rotate, p.box, 64, p.flip))
+            if p.base is None:          # null_transform
+                want = po.assemble_clip(frames, p.frames, p.rotate, p.box, 64, p.flip)
+            else:                       # base_transform on the resized 8-bit frames
+                u8 = np.stack([po.resize_bicubic(po.crop(po.transpose(frames[f], p.rotate), p.box), 64, 64) for f in p.frames])
+                want = po.base_transform_clip(u8, p.base, p.flip)
+            assert np.array_equal(c.cpu().numpy(), want)
         assert labels == [plan.spa_label, plan.tem_label, plan.pb_label, list(plan.rot_labels)]
 
 
@@ -109,3 +114,128 @@ def test_pretrain_driver_on_gpu_assembled_clips(tmp_path):
         v = dict(zip(head, r.split("\t")))
         assert np.isfinite(float(v["loss"]))
         assert 0.5 < float(v["loss_pred_spa"]) < 4 and 0.5 < float(v["loss_pred_rot"]) < 4
+
+
+# ---- the base_transform branch (preprocess_data.py:1110-1121): every GPU kernel np.array_equal to the Pillow call the reference makes
+def _clips():
+    g = np.random.default_rng(11)
+    smooth = np.clip(g.normal(128, 40, (3, 112, 112, 3)), 0, 255).astype(np.uint8)
+    return [g.integers(0, 256, (4, 112, 112, 3), dtype=np.uint8), smooth, g.integers(0, 256, (2, 37, 64, 3), dtype=np.uint8)]
+
+
+def _pil_frames(clip, fn):
+    return np.stack([np.asarray(fn(Image.fromarray(f, "RGB"))) for f in clip])
+
+
+def test_small_angle_rotation_is_pillow_bit_exact():
+    from cstp_amd import clip_ops
+    for clip in _clips():
+        dev = torch.from_numpy(clip).cuda()
+        for angle in (3.7, -9.99, 10.0, -10.0, 0.001, -0.5, 0.0, 45.0, 90.0, 180.0, 270.0, 359.2):
+            ref = _pil_frames(clip, lambda im: im.rotate(angle))
+            assert np.array_equal(clip_ops.clip_rotate(dev, angle).cpu().numpy(), ref), (clip.shape, angle)
+
+
+def test_colour_jitter_ops_are_pillow_bit_exact():
+    """adjust_brightness / _contrast / _saturation as torchvision's PIL backend performs them (ImageEnhance blends), adjust_hue
+    as its HSV round trip (functional_pil.py); the chains of tests/test_clip_oracle.py."""
+    from PIL import ImageEnhance
+    from cstp_amd import clip_ops
+    enh = {"brightness": ImageEnhance.Brightness, "contrast": ImageEnhance.Contrast, "saturation": ImageEnhance.Color}
+
+    def tv_hue(im, f):
+        h, s, v = im.convert("HSV").split()
+        nh = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            nh += np.array(f * 255).astype(np.uint8)
+        return Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB")
+    for clip in _clips():
+        dev = torch.from_numpy(clip).cuda()
+        for op, cls in enh.items():
+            for f in (0.6, 1.4, 0.0, 1.0, 1.0001, 0.73219, 1.39999):
+                ref = _pil_frames(clip, lambda im: cls(im).enhance(f))
+                assert np.array_equal(clip_ops.clip_colour(dev, op, f).cpu().numpy(), ref), (op, f)
+        for f in (0.1, -0.1, 0.05, -0.0371, 0.5, -0.5, 0.0):
+            ref = _pil_frames(clip, lambda im: tv_hue(im, f))
+            assert np.array_equal(clip_ops.clip_colour(dev, "hue", f).cpu().numpy(), ref), f
+
+
+def test_hsv_conversions_are_pillow_bit_exact_on_every_colour():
+    """All 2^24 RGB triples through RGB -> HSV and all 2^24 HSV triples through HSV -> RGB (Convert.c's float / double mix)."""
+    import ctypes
+    from cstp_amd import _lib
+    lib = _lib.load()
+    r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    cube = np.stack([r, g, b], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    dev = torch.from_numpy(cube).cuda()
+    out = torch.empty_like(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.cstp_clip_hue(st, dev.data_ptr(), out.data_ptr(), 4096 * 4096, 0, 1), "cstp_clip_hue")
+    assert np.array_equal(out.cpu().numpy(), np.asarray(Image.fromarray(cube).convert("HSV")))
+    _lib.check(lib.cstp_clip_hue(st, dev.data_ptr(), out.data_ptr(), 4096 * 4096, 0, 2), "cstp_clip_hue")
+    assert np.array_equal(out.cpu().numpy(), np.asarray(Image.fromarray(cube, "HSV").convert("RGB")))
+
+
+def test_channel_gray_and_gaussian_blur_are_pillow_bit_exact():
+    from PIL import ImageFilter
+    from cstp_amd import clip_ops
+    for clip in _clips():
+        dev = torch.from_numpy(clip).cuda()
+        chans = [i % 3 for i in range(clip.shape[0])]
+        ref = np.stack([np.repeat(f[:, :, c:c + 1], 3, axis=2) for f, c in zip(clip, chans)])
+        assert np.array_equal(clip_ops.clip_gray(dev, chans).cpu().numpy(), ref)
+        for sigma in list(np.linspace(0.1, 2.0, 20)) + [0.3, 1.0, 1.5, 3.7]:
+            ref = _pil_frames(clip, lambda im: im.filter(ImageFilter.GaussianBlur(radius=float(sigma))))
+            assert np.array_equal(clip_ops.clip_gaussian_blur(dev, float(sigma)).cpu().numpy(), ref), sigma
+            r_int, ww, fw = clip_ops.gaussian_box_weights(float(sigma))
+            assert r_int == int(po.gaussian_box_radius(float(sigma)))          # the host constants are the oracle's
+
+
+def test_base_transform_clips_match_pillow_chain_and_oracle():
+    """Whole clips through assemble_clip with base_transform draws (cstp_amd.sampler.base_draws): identical to the Pillow calls
+    chained as the reference chains them (crop -> resize, then rotate -> colour jitter in the drawn order -> channel gray ->
+    Gaussian blur -> flip -> tensor), and to the numpy oracle."""
+    from PIL import ImageEnhance, ImageFilter
+    from cstp_amd import clip_ops, sampler
+    enh = {"brightness": ImageEnhance.Brightness, "contrast": ImageEnhance.Contrast, "saturation": ImageEnhance.Color}
+    g = np.random.default_rng(3)
+    frames = g.integers(0, 256, (24, 96, 128, 3), dtype=np.uint8)
+    dev = torch.from_numpy(frames).cuda()
+    n_base = 0
+    for seed in range(40):
+        plan = sampler.sample_pair(24, 128, 96, 8, random.Random(seed), p_base=0.7, np_rng=np.random.RandomState(seed))
+        for cp in (plan.clip_1, plan.clip_2):
+            if cp.base is None:
+                continue
+            n_base += 1
+            got = clip_ops.assemble_clip(dev, cp, 112).cpu().numpy()
+            out = []
+            for i, f in enumerate(cp.frames):
+                im = Image.fromarray(frames[f], "RGB")
+                if cp.rotate:
+                    im = im.transpose(PIL_ROT[cp.rotate])
+                im = im.crop(cp.box).resize((112, 112), Image.BICUBIC)
+                im = im.rotate(cp.base.angle)
+                for op, fac in (cp.base.jitter or ()):
+                    if op == "hue":
+                        h, s, v = im.convert("HSV").split()
+                        nh = np.array(h, dtype=np.uint8)
+                        with np.errstate(over="ignore"):
+                            nh += np.array(fac * 255).astype(np.uint8)
+                        im = Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB")
+                    else:
+                        im = enh[op](im).enhance(fac)
+                if cp.base.gray is not None:
+                    c = np.array(im)[:, :, cp.base.gray[i]]
+                    im = Image.fromarray(np.dstack([c, c, c]), "RGB")
+                if cp.base.blur_sigma is not None:
+                    im = im.filter(ImageFilter.GaussianBlur(radius=cp.base.blur_sigma))
+                if cp.flip:
+                    im = im.transpose(Image.FLIP_LEFT_RIGHT)
+                out.append(po.to_tensor_tf(np.asarray(im)))
+            ref = np.stack(out, axis=1)
+            assert np.array_equal(got, ref), (seed, cp.base)
+            # ... and the oracle's own chain
+            u8 = np.stack([po.resize_bicubic(po.crop(po.transpose(frames[f], cp.rotate), cp.box), 112, 112) for f in cp.frames])
+            assert np.array_equal(po.base_transform_clip(u8, cp.base, cp.flip), ref)
+    assert n_base >= 20

@@ -1,4 +1,4 @@
-"""Pin the data-path oracle (oracle/pil_ops.py) bit-for-bit against Pillow -- the reference's image library, present in this
+"""Pin the data-path oracle (oracle/po.py) bit-for-bit against Pillow -- the reference's image library, present in this
 image -- and check the sampler's decisions (cstp_amd/sampler.py) against the invariants the reference code establishes.  CPU."""
 import random
 
@@ -53,10 +53,11 @@ def test_transposes_crop_and_tensor_match_pillow():
 def test_sampler_invariants():
     from cstp_amd import sampler
     seen_tem, seen_spa, seen_pb = set(), set(), set()
+    n_base, orders, kinds = 0, set(), set()
     for seed in range(300):
         rng = random.Random(seed)
         total = rng.choice([20, 40, 90, 150, 300])
-        plan = sampler.sample_pair(total, 171, 128, 16, rng)
+        plan = sampler.sample_pair(total, 171, 128, 16, rng, np_rng=np.random.RandomState(seed))
         a, b = plan.clip_1, plan.clip_2
         assert len(a.frames) == len(b.frames) == 16
         assert all(0 <= f < total for f in a.frames + b.frames)
@@ -86,9 +87,26 @@ def test_sampler_invariants():
         assert abs(ow * oh - rate_spa * w1 * h1) <= w1 + h1 + 1
         seen_tem.add(plan.tem_label); seen_spa.add(plan.spa_label); seen_pb.add(plan.pb_label)
         # a plan is a pure function of its arguments and seed
-        again = sampler.sample_pair(total, 171, 128, 16, random.Random(seed))
-        assert again.clip_1.frames != [] and (again.spa_label, again.tem_label, again.pb_label, again.rot_labels) is not None
+        rng2 = random.Random(seed)
+        assert rng2.choice([20, 40, 90, 150, 300]) == total
+        assert sampler.sample_pair(total, 171, 128, 16, rng2, np_rng=np.random.RandomState(seed)) == plan
+        # the base_transform draws (preprocess_data.py:1110-1119) stay inside the ranges the reference draws them from
+        for c in (a, b):
+            assert (c.base is not None) == c.use_base
+            if c.base is not None:
+                n_base += 1
+                assert -10 <= c.base.angle <= 10
+                if c.base.jitter is not None:
+                    assert sorted(o for o, _ in c.base.jitter) == ["brightness", "contrast", "hue", "saturation"]
+                    assert all((-0.1 <= f <= 0.1) if o == "hue" else (0.6 <= f <= 1.4) for o, f in c.base.jitter)
+                    orders.add(tuple(o for o, _ in c.base.jitter))
+                assert c.base.gray is None or (len(c.base.gray) == 16 and set(c.base.gray) <= {0, 1, 2})
+                assert c.base.blur_sigma is None or 0.1 <= c.base.blur_sigma <= 2.0
+                kinds.update([("jitter", c.base.jitter is not None), ("gray", c.base.gray is not None),
+                              ("blur", c.base.blur_sigma is not None)])
     assert seen_tem == {0, 1, 2, 3, 4} and seen_spa == {0, 1, 2, 3, 4} and seen_pb == {0, 1, 2, 3}
+    assert 0.2 * 600 < n_base < 0.4 * 600 and len(orders) > 6           # p = 0.3 per clip; the colour operations are shuffled
+    assert kinds == {(k, v) for k in ("jitter", "gray", "blur") for v in (True, False)}
 
 
 def test_sampler_draw_order_matches_the_reference_sequence():
@@ -103,6 +121,35 @@ def test_sampler_draw_order_matches_the_reference_sequence():
     assert (pb, (rot1, rot2)) == (plan.pb_label, plan.rot_labels)
     start = r.randint(1, total - 15 * sampler.PACE[pb])
     assert plan.clip_1.frames[0] == start - 1
+    # ... and through base_transform (:1110-1119): find a seed whose first clip takes the base branch with every option on, replay
+    for seed in range(400):
+        plan = sampler.sample_pair(total, 171, 128, t, random.Random(seed), np_rng=np.random.RandomState(seed))
+        bp = plan.clip_1.base
+        if bp is not None and bp.jitter is not None and bp.gray is not None and bp.blur_sigma is not None:
+            break
+    else:
+        raise AssertionError("no seed takes the full base branch")
+    r = random.Random(seed)
+    frames = sampler.sample_frames(total, t, r)
+    r.choices(range(2), weights=[1, 0])
+    assert (r.random() < 0.3) is True
+    r.random()                                              # clip 2's base-or-null draw
+    crop = sampler.OverlapCrop(r)
+    w1, h1 = (128, 171) if plan.clip_1.rotate in (90, 270) else (171, 128)
+    assert crop.first(w1, h1) == plan.clip_1.box
+    assert r.uniform(-10, 10) == bp.angle                   # RandomRotation
+    assert not 0.8 < r.random()                             # RandomApply(ColorJitter, p = 0.8) applies
+    r.random()                                              # ClipColorJitter's own p = 1.0 draw
+    ops = [("brightness", r.uniform(0.6, 1.4)), ("contrast", r.uniform(0.6, 1.4)), ("saturation", r.uniform(0.6, 1.4)),
+           ("hue", r.uniform(-0.1, 0.1))]
+    r.shuffle(ops)
+    assert ops == bp.jitter
+    assert r.random() < 0.2                                 # ClipRandomGray
+    assert [int(c) for c in np.random.RandomState(seed).choice(3, size=1)] == bp.gray[:1]
+    assert not 0.5 < r.random()                             # RandomApply(GaussianBlur, p = 0.5) applies
+    assert r.uniform(0.1, 2.0) == bp.blur_sigma
+    assert (r.random() < 0.5) == plan.clip_1.flip
+    assert frames[0] == plan.clip_1.frames
 
 
 def test_gpu_clip_loader_shards_without_a_gpu():
@@ -122,3 +169,59 @@ def test_gpu_clip_loader_shards_without_a_gpu():
     assert parts[0].indices() != idx[0]
     with pytest.raises(ValueError):
         GpuClipLoader(_DS(), 4, rank=3, world_size=3)
+
+
+# ---- the base_transform branch (preprocess_data.py:1110-1121): every numpy restatement bit-for-bit against the Pillow call the
+#      reference (or torchvision's PIL backend under it) makes -------------------------------------------------------------------
+def _imgs():
+    rng = np.random.RandomState(7)
+    smooth = np.clip(rng.randn(112, 112, 3) * 40 + 128, 0, 255).astype(np.uint8)
+    return [rng.randint(0, 256, (112, 112, 3), dtype=np.uint8), smooth, rng.randint(0, 256, (37, 64, 3), dtype=np.uint8)]
+
+
+def test_small_angle_rotation_matches_pillow():
+    """RandomRotation(10) :1060-1100 -> Image.rotate(angle): NEAREST, same size, black corners (Geometry.c affine_fixed)."""
+    for img in _imgs():
+        for angle in (3.7, -9.99, 10.0, -10.0, 0.001, -0.5, 0.0, 45.0, 90.0, 180.0, 270.0, 359.2):
+            ref = np.asarray(Image.fromarray(img).rotate(angle))
+            assert np.array_equal(po.rotate_nearest(img, angle), ref), (img.shape, angle)
+
+
+def test_colour_jitter_ops_match_pillow():
+    """ClipColorJitter :584-672 -> torchvision F.adjust_brightness / _contrast / _saturation = ImageEnhance blends,
+    F.adjust_hue = HSV round trip with a uint8 hue shift (torchvision/transforms/functional_pil.py)."""
+    from PIL import ImageEnhance
+    for img in _imgs():
+        pim = Image.fromarray(img)
+        for f in (0.6, 1.4, 0.0, 1.0, 1.0001, 0.73219, 1.39999):
+            assert np.array_equal(po.adjust_brightness(img, f), np.asarray(ImageEnhance.Brightness(pim).enhance(f)))
+            assert np.array_equal(po.adjust_contrast(img, f), np.asarray(ImageEnhance.Contrast(pim).enhance(f)))
+            assert np.array_equal(po.adjust_saturation(img, f), np.asarray(ImageEnhance.Color(pim).enhance(f)))
+        for f in (0.1, -0.1, 0.05, -0.0371, 0.5, -0.5, 0.0):
+            h, s, v = pim.convert("HSV").split()
+            nh = np.array(h, dtype=np.uint8)
+            with np.errstate(over="ignore"):
+                nh += np.array(f * 255).astype(np.uint8)
+            ref = Image.merge("HSV", (Image.fromarray(nh, "L"), s, v)).convert("RGB")
+            assert np.array_equal(po.adjust_hue(img, f), np.asarray(ref)), f
+
+
+def test_hsv_conversions_match_pillow_on_every_colour():
+    r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    cube = np.stack([r, g, b], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    assert np.array_equal(po.rgb_to_hsv(cube), np.asarray(Image.fromarray(cube).convert("HSV")))
+    assert np.array_equal(po.hsv_to_rgb(cube), np.asarray(Image.fromarray(cube, "HSV").convert("RGB")))
+    assert np.array_equal(po.rgb_to_l(cube), np.asarray(Image.fromarray(cube).convert("L")))
+
+
+def test_channel_gray_and_gaussian_blur_match_pillow():
+    """ClipRandomGray.grayscale :704-709; ClipGaussianBlur :675-687 -> ImageFilter.GaussianBlur(radius = sigma in [0.1, 2])."""
+    from PIL import ImageFilter
+    for img in _imgs():
+        for ch in range(3):
+            np_img = np.array(Image.fromarray(img))[:, :, ch]
+            ref = np.asarray(Image.fromarray(np.dstack([np_img, np_img, np_img]), "RGB"))
+            assert np.array_equal(po.channel_gray(img, ch), ref)
+        for rad in list(np.linspace(0.1, 2.0, 39)) + [0.3, 1.0, 1.5, 3.7]:
+            ref = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=float(rad))))
+            assert np.array_equal(po.gaussian_blur(img, float(rad)), ref), rad
