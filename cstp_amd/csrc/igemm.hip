@@ -898,7 +898,10 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
       p.w_mt = wt.m16 ? 9 : wt.mt;
       p.w_blocks = 256 * wt.wm;
       // igemm_k2s (3xbf16 split): 128- or 144-row tiles, 31-bit buffer offsets
-      p.w_split = wt.sp && !native_only() && !p.w_straddle && x_small && y_small && (wt.mt == 4 || wt.mt == 8 || wt.mt == 9);
+      // (the 3-channel stems: igemm_k2s<.., STR> over the zero-padded input copy, f16 pair only)
+      const bool stem_ok = split_planes() == 2 && p.ntaps * d.c <= STR_KMAX - 16 &&
+                           (size_t)d.n * d.c * (d.d + 2 * d.pt) * (d.h + 2 * d.ph) * (d.w + 2 * d.pw) < (1ull << 29);
+      p.w_split = wt.sp && !native_only() && (!p.w_straddle || stem_ok) && x_small && y_small && (wt.mt == 4 || wt.mt == 8 || wt.mt == 9);
       if (wt.sp && !p.w_split) p.w_mt = pick_mt(d.k);
     }
   }
@@ -958,6 +961,8 @@ static size_t plan_main_bytes(const cstp_conv_desc& d, const ConvPlan& p) {
   // the stems' split path keeps a zero-padded copy of the input behind the packed weights
   if (d.c < 8) f = align_up(f, 256) + align_up((size_t)d.n * d.c * (d.d + 2 * d.pt) * (d.h + 2 * d.ph) * (d.w + 2 * d.pw) * 4, 256);
   size_t w = align_up((size_t)d.k * p.w_Jp * sizeof(float), 256) * (deterministic() ? DET_MAX_SPLITS : 1);
+  // (the stems' split weight gradient keeps its zero-padded input copy behind the slab(s) and the absmax cells)
+  if (d.c < 8) w += 256 + align_up((size_t)d.n * d.c * (d.d + 2 * d.pt) * (d.h + 2 * d.ph) * (d.w + 2 * d.pw) * 4, 256);
   size_t m = f > g ? f : g;
   if (w > m) m = w;
   return align_up(m, 256);
@@ -1087,9 +1092,11 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
   hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
                      d.k, d.c, p.ntaps, d.c, Mp, Kp / 16, 0);
-  const size_t np = (size_t)d.n * d.c * Dq * Hq * Wq;
-  hipLaunchKernelGGL(pad_input_kernel, dim3(pack_grid(np / 4)), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph,
-                     d.pw);
+  {
+    const int nrows = d.n * d.c * Dq * Hq;
+    const int pgrid = nrows / 4 < 2048 ? (nrows + 3) / 4 : 2048;
+    hipLaunchKernelGGL(pad_input_kernel, dim3(pgrid), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph, d.pw);
+  }
   Geom g;
   g.Cs = d.c; g.Ds = Dq; g.Hs = Hq; g.Ws = Wq;
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;
@@ -1452,6 +1459,28 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
   const bool w_f16 = w_split && split_planes() == 2;
   const unsigned* xcell = x_absmax != nullptr ? x_absmax : cells;
   const unsigned* dycell = dy_absmax != nullptr ? dy_absmax : cells + 1;
+  if (w_split && p.w_straddle) {
+    // the stem: zero-padded copy of x behind the slab(s) + cells (its absmax is the pad kernel's by-product), columns (tap, c)
+    const int Dq = d.d + 2 * d.pt, Hq = d.h + 2 * d.ph, Wq = d.w + 2 * d.pw;
+    float* xp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slabs_bytes + 256);
+    const int nrows = d.n * d.c * Dq * Hq;
+    const int pgrid = nrows / 4 < 2048 ? (nrows + 3) / 4 : 2048;
+    hipLaunchKernelGGL(pad_input_kernel, dim3(pgrid), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph, d.pw);
+    const size_t ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
+    if (dy_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s, dy, ny, cells + 1);
+    Geom gs = g;
+    gs.Ds = Dq; gs.Hs = Hq; gs.Ws = Wq; gs.pt = 0; gs.ph = 0; gs.pw = 0; gs.Cp = d.c;
+#define CSTP_K2S_STR(MT_) \
+  hipLaunchKernelGGL((igemm_k2s<MT_, 2, true>), grid, dim3(512), 0, s, gs, dy, xp, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, cells, dycell, det_stride)
+    if (p.w_mt == 9) CSTP_K2S_STR(9); else if (p.w_mt == 4) CSTP_K2S_STR(4); else CSTP_K2S_STR(8);
+#undef CSTP_K2S_STR
+    CSTP_LAUNCH_CHECK();
+    const size_t tot_s = (size_t)d.k * d.c * p.ntaps;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot_s)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp,
+                       cells, dycell, det ? splits : 1, det_stride, accumulate ? 1 : 0);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   if (w_split) {
 #define CSTP_K2S(MT_, NP_) \
   hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell, det_stride)
@@ -1610,6 +1639,12 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
       if (!stem && d.k > 128 && d.k <= 144) wc[nw++] = Tile{9, blocks, 1};
       for (int mt = 2; mt <= 5; ++mt)
         if (mt != base && cdiv(d.k, 32 * mt) * 32 * mt <= cdiv(d.k, 32 * base) * 32 * base + 16 && nw < 15) wc[nw++] = Tile{mt, blocks, 0};
+    }
+    if (allow_split2 && stem && split_planes() == 2 && d.k >= 48) {      // the stems on igemm_k2s<.., STR> (f16 pair)
+      int smt = 4, pad = cdiv(d.k, 64) * 64 - d.k;
+      if (cdiv(d.k, 128) * 128 - d.k <= pad) { smt = 8; pad = cdiv(d.k, 128) * 128 - d.k; }
+      if (cdiv(d.k, 144) * 144 - d.k < pad) smt = 9;
+      for (int blocks = 4; blocks <= 16; blocks *= 2) wc[nw++] = Tile{smt, blocks, 0, 0, 1};
     }
     if (allow_split2 && !stem && d.k >= 48) {      // igemm_k2s: 64- / 128- / 144-row tiles, whichever pads the rows least
       int smt = 4, pad = cdiv(d.k, 64) * 64 - d.k;

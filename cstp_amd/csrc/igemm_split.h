@@ -229,28 +229,32 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
 __global__ void __launch_bounds__(256)
 pad_input_kernel(const float* __restrict__ x, float* __restrict__ xp, unsigned* __restrict__ cell, int planes, int D, int H,
                  int W, int pt, int ph, int pw) {
-  // xp[plane][D + 2pt][H + 2ph][W + 2pw] = x[plane][D][H][W] inside, 0 around; *cell = max |x| (fp32 bits) as a by-product
+  // xp[plane][D + 2pt][H + 2ph][W + 2pw] = x[plane][D][H][W] inside, 0 around; *cell = max |x| (fp32 bits) as a by-product.
+  // One WAVE per padded row at a time (coalesced along w, the row decoded once per wave): the first version decoded every
+  // element with three 64-bit divisions and ran at 0.8 TB/s -- as long as the stem's GEMM itself.
   const int Dq = D + 2 * pt, Hq = H + 2 * ph, Wq = W + 2 * pw;
-  const size_t total = (size_t)planes * Dq * Hq * Wq;
+  const int nrows = planes * Dq * Hq;
+  const int lane = threadIdx.x & 63;
   unsigned mx = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int w = (int)(i % Wq);
-    size_t r = i / Wq;
-    const int h = (int)(r % Hq);
-    r /= Hq;
-    const int d = (int)(r % Dq);
-    const size_t pl = r / Dq;
-    const int id = d - pt, ih = h - ph, iw = w - pw;
-    float v = 0.f;
-    if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-      v = x[((pl * D + id) * H + ih) * W + iw];
-    xp[i] = v;
-    const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
-    mx = mx > a ? mx : a;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
+    const int h = row % Hq, r2 = row / Hq;
+    const int d = r2 % Dq, pl = r2 / Dq;
+    const int id = d - pt, ih = h - ph;
+    const bool in = (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H;
+    const float* src = x + ((size_t)(pl * D + (in ? id : 0)) * H + (in ? ih : 0)) * W;
+    float* dst = xp + (size_t)row * Wq;
+    for (int w = lane; w < Wq; w += 64) {
+      const int iw = w - pw;
+      float v = 0.f;
+      if (in && (unsigned)iw < (unsigned)W) v = src[iw];
+      dst[w] = v;
+      const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+      mx = mx > a ? mx : a;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
-  if ((threadIdx.x & 63) == 0 && mx != 0) atomicMax(cell, mx);
+  if (lane == 0 && mx != 0) atomicMax(cell, mx);
 }
 
 constexpr int STR_KMAX = 1056;                       // table entries: 7x7x7 taps x 3 channels = 1029, padded to 16
@@ -701,7 +705,10 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 // out-of-range buffer offsets = zeros.  Tile (16*MT) x 128 outputs, K-tile 32 positions, split-K with f32 atomics as K2.
 // NP as in igemm_k1s; NP == 2: *xcell / *dycell = largest magnitude of x / dY, the slab receives the SCALED sums and
 // unpack_wgrad_kernel multiplies by the inverse powers of two.
-template <int MT, int NP>
+// STR (NP == 2 only): layers with fewer than 8 input channels (the 3-channel stems).  The columns run j = tap * Cs + c with NO
+// channel padding (147 columns for the 1x7x7 stem instead of 49 taps x 32), the source is the ZERO-PADDED copy of x
+// (pad_input_kernel), and each of a producer's 16 columns has its own constant offset from the position's base.
+template <int MT, int NP, bool STR = false>
 __global__ void __launch_bounds__(512, NP == 2 ? 4 : 1)      // f16 pair: the LDS images fit twice into a CU (4 waves per SIMD: <= 128 VGPRs)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
           int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit, const unsigned* __restrict__ xcell,
@@ -778,12 +785,26 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       c0 = jg - tap * g.Cp;
       if (tap >= ntaps) tap = ntaps - 1;
     }
-    const int dt = tap / khw, rr_ = tap - dt * khw, dh = rr_ / g.kw, dw = rr_ - dh * g.kw;
+    int dt = tap / khw, rr_ = tap - dt * khw, dh = rr_ / g.kw, dw = rr_ - dh * g.kw;
+    if constexpr (STR) {
+      // my 16 columns (tap, channel) of the padded source, each a constant offset from the position's base; columns past
+      // the last one repeat it (finite values in slab cells nobody reads)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int c = c0 + j;
-      c = c < g.Cs ? c : g.Cs - 1;
-      coff[j] = (unsigned)c * (unsigned)DHWs * 4u;
+      for (int j = 0; j < 16; ++j) {
+        int col = j0 + 16 * q + j;
+        col = col < Jtot ? col : Jtot - 1;
+        const int tp2 = col / g.Cs, c = col - tp2 * g.Cs;
+        const int t2 = tp2 / khw, r2 = tp2 - t2 * khw, h2 = r2 / g.kw, w2 = r2 - h2 * g.kw;
+        coff[j] = (unsigned)(((c * g.Ds + t2) * g.Hs + h2) * g.Ws + w2) * 4u;
+      }
+      dt = dh = dw = 0;                              // (the tap offsets live in coff; the source has no halo to check)
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        int c = c0 + j;
+        c = c < g.Cs ? c : g.Cs - 1;
+        coff[j] = (unsigned)c * (unsigned)DHWs * 4u;
+      }
     }
     // LDS slots (uint2 index inside one plane) of my stores
     const int a_slot = r * 32 + pc(r, 4 * q);        // 4 pieces = 32 contiguous bytes (the swizzle permutes whole 32-B

@@ -553,3 +553,39 @@ def test_stem_on_the_split_kernel(name, mt):
     finally:
         ops.set_split_terms(0)
         del GEOMS["_stem"]
+
+
+@pytest.mark.parametrize("mt,blocks", [(4, 4), (8, 8), (9, 16)])
+@pytest.mark.parametrize("name", list(STEMS))
+def test_stem_weight_gradient_on_the_split_kernel(name, mt, blocks):
+    """igemm_k2s<.., STR>: the stems' weight gradient over the zero-padded input copy, columns (tap, channel) without channel
+    padding (round 3); pinned, queried back, scale-invariant, and bit-reproducible in the deterministic mode."""
+    import ctypes
+    from cstp_amd import _lib, ops
+    GEOMS["_stem"] = STEMS[name]
+    xs, k, ks, st, pd = STEMS[name]
+    ops.set_split_terms(2)
+    try:
+        _run("_stem", {0: (0, 2, 1, 1), 2: (1, mt, blocks, 0)})
+        out = (ctypes.c_int32 * 4)()
+        desc = ops._desc(xs, (k, xs[1]) + ks, st, pd)
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(desc), 2, out), "query")
+        assert list(out) == [16 * mt, 128, 2, blocks]
+        _run("_stem", {0: (0, 2, 1, 1), 2: (1, mt, blocks, 0)}, scale_x=3e15, scale_dy=1e-9)
+        ops.set_deterministic(True)
+        try:
+            lib = _lib.load()
+            x, dy = _rand(xs, 31).float().cuda(), None
+            w = torch.zeros((k, xs[1]) + ks)
+            dy = _rand(F.conv3d(x.cpu().double(), w.double(), None, st, pd).shape, 33).float().cuda()
+            runs = []
+            for _ in range(2):
+                dw = torch.empty(w.shape, device="cuda")
+                _wgrad_call(lib, ops, desc, x, dy, dw, 0)
+                runs.append(dw)
+            assert torch.equal(runs[0], runs[1])
+        finally:
+            ops.set_deterministic(False)
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_stem"]
