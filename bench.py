@@ -51,7 +51,7 @@ ARITH_NAME = {0: "native f32 MFMA", 1: "native f32 MFMA", 2: "2xf16-split (22-bi
 DEPTH, B_LOCAL, T, HW = 18, 16, 16, 112
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 0.0, 0.0)
 NTXENT_WEIGHT = 1.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_dominant_kernel.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_dominant_kernel.json")
 
 
 class KernelTimers:
@@ -139,15 +139,17 @@ def cpu_baseline(sample_b=2, timed=3):
     sd = orc.closed_form_state(ls, torch.float32)
     mom = {}
     x1, x2, labels = orc.closed_form_clips(sample_b, T, HW, torch.float32)
-    w = (0.1, 1.0, 1.0, 1.0, 1.0)
-    orc.train_step(sd, mom, x1, x2, labels, ls, 0.01, 0.9, 5e-4, w, True)          # warm-up
+    # the SAME objective as the GPU line: loss_weight (0.1, 1, 1, 0, 0) + 1 x NT-Xent on the online projections (configs[1])
+    kw = dict(ntxent_weight=NTXENT_WEIGHT, temperature=0.5)
+    orc.train_step(sd, mom, x1, x2, labels, ls, 0.01, 0.9, 5e-4, LOSS_WEIGHT, True, **kw)          # warm-up
     t0 = time.time()
     for _ in range(timed):
-        orc.train_step(sd, mom, x1, x2, labels, ls, 0.01, 0.9, 5e-4, w, True)
+        orc.train_step(sd, mom, x1, x2, labels, ls, 0.01, 0.9, 5e-4, LOSS_WEIGHT, True, **kw)
     dt = (time.time() - t0) / timed
     return {"value": sample_b / dt, "unit": "clips/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
-            "sample": "R(2+1)D-18 full step (fwd+bwd+clip+SGD+EMA), B=%d of %d clip pairs 3x%dx%dx%d, 1 warm-up + %d timed "
-                      "steps, %.1f s per step" % (sample_b, B_LOCAL, T, HW, HW, timed, dt)}
+            "sample": "R(2+1)D-18 full step (fwd+bwd+clip+SGD+EMA; the GPU line's objective: BYOL + overlap heads + NT-Xent), "
+                      "B=%d of %d clip pairs 3x%dx%dx%d, 1 warm-up + %d timed steps, %.1f s per step"
+                      % (sample_b, B_LOCAL, T, HW, HW, timed, dt)}
 
 
 def conv_work(n, c, d, h, w, k, kt, kh, kw, st, sh, sw, pt, ph, pw):

@@ -43,6 +43,7 @@ SIGNATURES = {
     "cstp_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t]),
     "cstp_conv3d_forward_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, POINTER(InAffine), _P, _P, c_size_t, _P]),
     "cstp_conv3d_backward_data_am": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "cstp_conv3d_backward_data_acc": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, c_int32]),
     "cstp_conv3d_backward_weight_am": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P]),
     "cstp_conv3d_backward_weight_acc": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P,
                                                  c_int32]),

@@ -55,6 +55,7 @@ struct Geom {
   int M;                   // valid GEMM rows
   int Mp;                  // leading dimension of the packed A operand
   int Ktot;                // ntaps * Cp
+  int acc = 0;             // forward / data-gradient kernels: out += instead of out = (the caller's gradient accumulation)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -411,8 +412,16 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         float ve = odd ? recv : v0;                    // row m_even: own cols 0-15 | partner's cols 16-31
         float vo = odd ? v1 : recv;                    // row m_odd
         // streaming (nt) stores: the output is not re-read by this kernel, keep the L2 for the input halo rows
-        if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
-        if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
+        if (nok && m_even < g.M) {
+          if (bias != nullptr) ve += bias[m_even];
+          if (g.acc) ve += out[obase + (size_t)m_even * cstride];
+          CSTP_STORE(out + obase + (size_t)m_even * cstride, ve);
+        }
+        if (nok && m_odd < g.M) {
+          if (bias != nullptr) vo += bias[m_odd];
+          if (g.acc) vo += out[obase + (size_t)m_odd * cstride];
+          CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo);
+        }
       }
     }
     return;
@@ -443,6 +452,7 @@ igemm_k1(const Geom g, const float* __restrict__ wp, const float* __restrict__ s
         if (m < g.M) {
           float v = acc[mt][r];
           if (bias != nullptr) v += bias[m];
+          if (g.acc) v += out[obase + (size_t)m * cstride];
           CSTP_STORE(out + obase + (size_t)m * cstride, v);
         }
       }
@@ -1129,8 +1139,10 @@ static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups)
 }
 
 static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
-                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax, const K1pStats* st = nullptr) {
+                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax, const K1pStats* st = nullptr,
+                    bool accumulate = false) {
   PGeom g;
+  g.acc = accumulate ? 1 : 0;
   g.gpos = st ? (int)((long)(d.n / st->groups) * d.d * d.h * d.w) : 1;
   g.groups = st ? st->groups : 1;
   g.Cs = dgrad ? d.k : d.c;
@@ -1333,6 +1345,12 @@ extern "C" int cstp_conv3d_backward_data(void* stream, const cstp_conv_desc* des
 
 extern "C" int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
                                             float* dx, void* ws, size_t ws_bytes, const uint32_t* dy_absmax) {
+  return cstp_conv3d_backward_data_acc(stream, desc, dy, w, dx, ws, ws_bytes, dy_absmax, 0);
+}
+
+extern "C" int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w,
+                                             float* dx, void* ws, size_t ws_bytes, const uint32_t* dy_absmax,
+                                             int32_t accumulate) {
   CSTP_REQUIRE(desc && dy && w && dx && ws, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1343,7 +1361,7 @@ extern "C" int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* 
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
   if (p.d_t.sp == 2) {
-    run_k1p(p.d_t, s, d, true, w, dy, dx, ws, plan_main_bytes(d, p), dy_absmax);
+    run_k1p(p.d_t, s, d, true, w, dy, dx, ws, plan_main_bytes(d, p), dy_absmax, nullptr, accumulate != 0);
     CSTP_LAUNCH_CHECK();
     return 0;
   }
@@ -1357,6 +1375,7 @@ extern "C" int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* 
   g.Nb = d.n; g.Dp = d.d; g.Hp = d.h; g.Wp = d.w;         // FULL x dims; classes subsample inside
   g.kt = d.kt; g.kh = d.kh; g.kw = d.kw; g.st = d.st; g.sh = d.sh; g.sw = d.sw; g.pt = d.pt; g.ph = d.ph; g.pw = d.pw;
   g.Cp = p.d_Cp; g.M = d.c; g.Mp = p.d_Mp; g.Ktot = p.ntaps * p.d_Cp;
+  g.acc = accumulate ? 1 : 0;
   const int nclass = d.st * d.sh * d.sw;
   const int npos_max = d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw);
   const int d_bm = tile_bm(p.d_t), d_bn = tile_bn(p.d_t);

@@ -52,6 +52,7 @@ struct PGeom {
   int rows_lds;     // LDS rows a tile can touch (<= KP_ROWS)
   int gpos;         // STATS: output positions per BatchNorm group (a multiple of KP_NPOS: no tile straddles two groups)
   int groups;       // STATS: BatchNorm groups (<= 2)
+  int acc = 0;      // out += instead of out = (the caller's gradient accumulation; data gradient)
 };
 
 // packed weights for igemm_k1p: wpk[mblk][kt = cb * 9 + tap][row (16*MT)][physical chunk (8)][8 f16], row m scaled by a power of
@@ -594,7 +595,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
           const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
           if ((KP_DIAG & 8) && v[0] != 12345.f) continue;
-          if (nok[j] && m < g.M) *reinterpret_cast<f32x4*>(orow + obase[j]) = v * sc;
+          if (nok[j] && m < g.M) {
+            f32x4* dst = reinterpret_cast<f32x4*>(orow + obase[j]);
+            *dst = g.acc ? *dst + v * sc : v * sc;
+          }
           if constexpr (STATS) { const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv; }     // (every position of every tile is valid: host condition)
         }
         if constexpr (STATS) {
@@ -633,7 +637,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if ((KP_DIAG & 8) && v[r] != 12345.f) continue;
-            if (nk[r] && m < g.M) CSTP_STORE(out + ob[r] + (size_t)m * chs, v[r] * sc);
+            if (nk[r] && m < g.M) {
+              float* dst = out + ob[r] + (size_t)m * chs;
+              CSTP_STORE(dst, g.acc ? *dst + v[r] * sc : v[r] * sc);
+            }
           }
         }
       }

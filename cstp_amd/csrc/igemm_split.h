@@ -682,8 +682,16 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
         float ve = odd ? recv : v0;
         float vo = odd ? v1 : recv;
         if (NP == 2) { ve *= ia0[r]; vo *= ia1[r]; }
-        if (nok && m_even < g.M) { if (bias != nullptr) ve += bias[m_even]; CSTP_STORE(out + obase + (size_t)m_even * cstride, ve); }
-        if (nok && m_odd < g.M) { if (bias != nullptr) vo += bias[m_odd]; CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo); }
+        if (nok && m_even < g.M) {
+          if (bias != nullptr) ve += bias[m_even];
+          if (g.acc) ve += out[obase + (size_t)m_even * cstride];
+          CSTP_STORE(out + obase + (size_t)m_even * cstride, ve);
+        }
+        if (nok && m_odd < g.M) {
+          if (bias != nullptr) vo += bias[m_odd];
+          if (g.acc) vo += out[obase + (size_t)m_odd * cstride];
+          CSTP_STORE(out + obase + (size_t)m_odd * cstride, vo);
+        }
       }
     }
   }

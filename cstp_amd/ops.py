@@ -337,11 +337,37 @@ def _new_cell(like: torch.Tensor) -> Optional[torch.Tensor]:
     return torch.empty(1, dtype=torch.int32, device=like.device) if FUSE_ABSMAX else None
 
 
+class GradJoin:
+    """The gradients of ONE tensor that feeds ``n`` of these ops (the residual connection, r21d_byol.py:141-148: a block's
+    input goes into conv1 AND into the addition behind bn2; in a downsample block into conv1 and the shortcut convolution)
+    are summed inside the ops instead of by autograd's separate add pass over three tensors: every contributor but the last
+    puts its gradient into the join's buffer (the first one creates it, convolutions after that ADD into it in their
+    epilogue: cstp_conv3d_backward_data_acc) and hands autograd None; the last one adds its own and returns the sum.
+    A fresh object per forward call; backward order is whatever the autograd engine chooses."""
+
+    def __init__(self, n: int):
+        self.n, self.count, self.buf = int(n), 0, None
+
+    def contribute(self, plain, accumulate):
+        """``plain() -> fresh gradient tensor``; ``accumulate(buf)``: buf += this contributor's gradient."""
+        self.count += 1
+        if self.buf is None:
+            out = plain()
+        else:
+            accumulate(self.buf)
+            out = self.buf
+        if self.count < self.n:
+            self.buf = out
+            return None
+        self.buf, self.count = None, 0
+        return out
+
+
 class _Conv3d(torch.autograd.Function):
     _last_stats = None
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, bn_groups=0, bn_pivot=None):
+    def forward(ctx, x, w, bias, stride, padding, bn_groups=0, bn_pivot=None, grad_join=None):
         lib = _lib.load()
         xam = _absmax_of(x)
         w_in = w
@@ -375,6 +401,7 @@ class _Conv3d(torch.autograd.Function):
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
         ctx.save_for_backward(x, w)
         ctx.w_param = w_in           # the parameter object itself (save_for_backward hands back a new tensor object)
+        ctx.grad_join = grad_join
         ctx.x_absmax = xam
         ctx.desc = desc
         ctx.has_bias = bias is not None
@@ -421,13 +448,19 @@ class _Conv3d(torch.autograd.Function):
             _queue_join(x.device)
         ws = _workspace(x.device, nbytes)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            if AUTOTUNE:
-                _autotune(lib, desc, 1, dy, w, dx, ws)
-            with _span("conv3d_backward_data", lambda: _desc_key(desc)):
-                check(lib.cstp_conv3d_backward_data_am(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
-                                                       dx.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(dyam)),
-                      "cstp_conv3d_backward_data")
+            def dgrad(dst, acc):
+                if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
+                    _autotune(lib, desc, 1, dy, w, torch.empty_like(dst) if acc else dst, ws)   # (tuning overwrites its output)
+                with _span("conv3d_backward_data", lambda: _desc_key(desc)):
+                    check(lib.cstp_conv3d_backward_data_acc(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
+                                                            dst.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(dyam), 1 if acc else 0),
+                          "cstp_conv3d_backward_data")
+                return dst
+            join = ctx.grad_join
+            if join is None:
+                dx = dgrad(torch.empty_like(x), False)
+            else:       # x also feeds another op: the sum of the two gradients is formed here (GradJoin)
+                dx = join.contribute(lambda: dgrad(torch.empty_like(x), False), lambda buf: dgrad(buf, True))
         if direct_w and not side_w:
             wgrad_into_arena()
         elif ctx.needs_input_grad[1] and not direct_w:
@@ -443,14 +476,15 @@ class _Conv3d(torch.autograd.Function):
             s = dy.numel() // (n * k)
             db = torch.empty(k, dtype=torch.float32, device=dy.device)
             check(lib.cstp_channel_sum(_stream(), dy.data_ptr(), db.data_ptr(), n, k, s, None, 0), "cstp_channel_sum")
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None):
+def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None, grad_join=None):
     """F.conv3d drop-in (fp32, NCDHW).  ``bn_groups`` > 0: the caller feeds the result to a train-mode ``batch_norm_act`` with
     that many groups -- the convolution then leaves the BatchNorm's statistics beside its output where its kernel can.
-    ``bn_pivot`` ([C_out], e.g. that BatchNorm's running_mean): the sums are taken around it (cstp_conv3d_forward_bnstats)."""
-    y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups), bn_pivot)
+    ``bn_pivot`` ([C_out], e.g. that BatchNorm's running_mean): the sums are taken around it (cstp_conv3d_forward_bnstats).
+    ``grad_join``: x also feeds another op of this module that was given the same GradJoin (see there)."""
+    y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups), bn_pivot, grad_join)
     st = _Conv3d._last_stats
     _Conv3d._last_stats = None
     if st is not None:
@@ -468,7 +502,7 @@ def _bnstats_of(t, groups):
 def linear(x, w, bias=None):
     """F.linear drop-in for 2-D x: the 1x1x1 convolution over [B][F][1][1][1]."""
     y = _Conv3d.apply(x.reshape(x.shape[0], x.shape[1], 1, 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1, 1), bias,
-                      (1, 1, 1), (0, 0, 0), 0, None)
+                      (1, 1, 1), (0, 0, 0), 0, None, None)
     return y.reshape(x.shape[0], w.shape[0])
 
 
@@ -480,7 +514,7 @@ class _BNAct(torch.autograd.Function):
     _pre_stats = None     # (partial sums, nsplit) the producing convolution left for this call (batch_norm_act sets it)
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups, grad_join=None):
         lib = _lib.load()
         x = _req(x, "batch_norm input")
         gamma = _req(gamma, "batch_norm weight")
@@ -525,6 +559,7 @@ class _BNAct(torch.autograd.Function):
         ctx.groups = groups
         ctx.has_res = res is not None
         ctx.params = (gamma, beta)     # the parameter objects themselves (their .grad may be an arena slice, see backward)
+        ctx.grad_join = grad_join
         return y
 
     @staticmethod
@@ -551,18 +586,20 @@ class _BNAct(torch.autograd.Function):
                                           dbeta.data_ptr(), n, c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(),
                                           _ptr(cell), 1 if direct else 0), "cstp_bn_backward")
         _tag_absmax(dx, cell)
+        if dres is not None and ctx.grad_join is not None:       # the residual tensor's other consumer adds its gradient to this
+            dres = ctx.grad_join.contribute(lambda: dres, lambda buf: buf.add_(dres))
         if direct:
-            return dx, None, None, dres, None, None, None, None, None, None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+            return dx, None, None, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual=None, relu=False, eps=BN_EPS,
-                   momentum=BN_MOMENTUM, groups=1):
+                   momentum=BN_MOMENTUM, groups=1, grad_join=None):
     """y = act(batch_norm_train(x) + residual); running stats updated in place.  ``groups`` > 1: the batch is
     that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
     _BNAct._pre_stats = _bnstats_of(x, int(groups))
     y = _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
-                     int(groups))
+                     int(groups), grad_join)
     _tag_absmax(y, _BNAct._last_cell)
     _BNAct._last_cell = None
     return y

@@ -89,10 +89,10 @@ class Conv3d(nn.Module):
         self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Conv3d.reset_parameters
 
-    def forward(self, x, bn_groups=0, bn_pivot=None):
+    def forward(self, x, bn_groups=0, bn_pivot=None, grad_join=None):
         """``bn_groups`` > 0: a train-mode BatchNorm with that many groups consumes the result; ``bn_pivot``: its running
-        mean, the value its statistics are summed around (ops.conv3d)."""
-        return ops.conv3d(x, self.weight, None, self.stride, self.padding, bn_groups, bn_pivot)
+        mean, the value its statistics are summed around; ``grad_join``: x feeds a second op too (ops.conv3d)."""
+        return ops.conv3d(x, self.weight, None, self.stride, self.padding, bn_groups, bn_pivot, grad_join)
 
 
 class _BatchNorm(nn.Module):
@@ -108,14 +108,14 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, residual=None, relu=False, groups=1):
+    def forward(self, x, residual=None, relu=False, groups=1, grad_join=None):
         if not self.training:   # model.eval(): running statistics, nothing updated (validation / test)
             return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
         if x.numel() // x.shape[1] // groups <= 1:
             # same failure the reference hits in nn.BatchNorm*d (train mode)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
         y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps,
-                               self.momentum, groups)
+                               self.momentum, groups, grad_join)
         if not getattr(self, "_nbt_in_arena", False):
             self.num_batches_tracked += groups   # else: one add per net per forward, see R21DBYOL.forward
         return y
@@ -195,8 +195,9 @@ class SpatioTemporalConv(nn.Module):
         self.temporal_conv = Conv3d(intermed_channels, out_channels, (kernel_size[0], 1, 1), stride=(stride[0], 1, 1),
                                     padding=(padding[0], 0, 0), bias=bias)
 
-    def forward(self, x, groups=1, pre_bn=None):
-        """temporal_conv(relu(bn(spatial_conv(x)))) (r21d_byol.py:94-97).  ``pre_bn``: the BatchNorm whose
+    def forward(self, x, groups=1, pre_bn=None, grad_join=None):
+        """temporal_conv(relu(bn(spatial_conv(x)))) (r21d_byol.py:94-97).  ``grad_join``: x feeds a second op of the block
+        as well (the residual / the shortcut): their gradients are summed inside the ops (ops.GradJoin).  ``pre_bn``: the BatchNorm whose
         apply+ReLU precedes this module in the block (bn1 -> relu1 -> conv2, :142-143).
         With FUSE_BN_INTO_CONV each BN+ReLU is folded into the following convolution's gather (the normalised
         tensor is never written: -36 % BN traffic, -7 ms/step of BN kernels, -7 GB of activations at cfg2) --
@@ -207,7 +208,8 @@ class SpatioTemporalConv(nn.Module):
             return self.bn.relu_then(self.temporal_conv, x, groups)
         if pre_bn is not None:
             x = pre_bn(x, relu=True, groups=groups)
-        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean), relu=True, groups=groups)
+        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean,
+                                      grad_join if pre_bn is None else None), relu=True, groups=groups)
         return self.temporal_conv(x)
 
 
@@ -229,11 +231,15 @@ class SpatioTemporalResBlock(nn.Module):
         self.outrelu = ReLU()
 
     def forward(self, x, groups=1):
-        res = self.conv2(self.conv1(x, groups), groups, pre_bn=self.bn1)   # conv2(relu1(bn1(conv1(x))))
+        # the block's input feeds two ops -- conv1 and the residual addition (or, in a downsample block, conv1 and the shortcut
+        # convolution): their two gradients are summed inside the second op's kernel instead of by a separate add pass
+        join = ops.GradJoin(2) if (self.training and torch.is_grad_enabled() and x.requires_grad and not FUSE_BN_INTO_CONV) else None
+        res = self.conv2(self.conv1(x, groups, grad_join=join), groups, pre_bn=self.bn1)   # conv2(relu1(bn1(conv1(x))))
         if self.downsample:
-            x = self.downsamplebn(self.downsampleconv(x, groups), groups=groups)
+            x = self.downsamplebn(self.downsampleconv(x, groups, grad_join=join), groups=groups)
+            join = None
         # relu(x + bn2(res)) as one kernel (r21d_byol.py:143,148)
-        return self.bn2(res, residual=x, relu=True, groups=groups)
+        return self.bn2(res, residual=x, relu=True, groups=groups, grad_join=join)
 
 
 class SpatioTemporalResLayer(nn.Module):

@@ -94,6 +94,11 @@ int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const 
                                 size_t part_bytes, int32_t* nsplit);
 int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
                                  void* ws, size_t ws_bytes, const uint32_t* dy_absmax);
+/* ... and with accumulate != 0: dx += the data gradient instead of dx = -- autograd's sum of the gradients of a tensor that
+ * feeds two consumers (the residual connection, r21d_byol.py:141-148: x goes into conv1 AND into the addition behind bn2),
+ * folded into the convolution's epilogue: one extra read of dx instead of a separate three-tensor add pass. */
+int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
+                                  void* ws, size_t ws_bytes, const uint32_t* dy_absmax, int32_t accumulate);
 int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc* desc, const float* x, const cstp_in_affine* in_affine,
                                    const float* dy, float* dw, void* ws, size_t ws_bytes, const uint32_t* x_absmax,
                                    const uint32_t* dy_absmax);

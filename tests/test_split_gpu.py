@@ -589,3 +589,40 @@ def test_stem_weight_gradient_on_the_split_kernel(name, mt, blocks):
     finally:
         ops.set_split_terms(0)
         del GEOMS["_stem"]
+
+
+@pytest.mark.parametrize("name,tile", [("S1", (2, 4, 0, 0)), ("S1", (1, 4, 0, 0)), ("S1", (0, 2, 1, 1)), ("S2s", (1, 9, 0, 0)),
+                                       ("S2s", (0, 2, 2, 1)), ("T2s", (1, 4, 0, 0)), ("odd", (1, 3, 0, 0)), ("lin", (1, 2, 0, 0))],
+                         ids=["patch", "split", "native", "split strided", "native strided", "split temporal strided", "split odd",
+                              "split linear"])
+def test_data_gradient_accumulate_flag(name, tile):
+    """cstp_conv3d_backward_data_acc: dx += the data gradient (the sum of a residual connection's two gradients formed in the
+    convolution's epilogue, ops.GradJoin) on every kernel family, incl. the stride-parity classes of a strided layer."""
+    import ctypes
+    from cstp_amd import _lib, ops
+    lib = _lib.load()
+    xs, k, ks, st, pd = GEOMS[name] if name != "S1" else (PATCH_GEOMS["S1big"][0], PATCH_GEOMS["S1big"][1], (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.set_split_terms(2)
+    try:
+        x = _rand(xs, 41).requires_grad_(True)
+        w = (_rand((k, xs[1]) + ks, 42) * 0.2)
+        y = F.conv3d(x, w, None, st, pd)
+        dy = _rand(y.shape, 43)
+        y.backward(dy)
+        ops.set_conv_tile(xs, tuple(w.shape), st, pd, 1, tile)
+        desc = ops._desc(xs, tuple(w.shape), st, pd)
+        ws = torch.empty(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), dtype=torch.uint8, device="cuda")
+        base = _rand(xs, 44).float().cuda()
+        dx = base.clone()
+        call = lambda acc: _lib.check(lib.cstp_conv3d_backward_data_acc(   # noqa: E731
+            torch.cuda.current_stream().cuda_stream, ctypes.byref(desc), dy.float().cuda().data_ptr(), w.float().cuda().data_ptr(),
+            dx.data_ptr(), ws.data_ptr(), ws.numel(), None, acc), "cstp_conv3d_backward_data_acc")
+        dyg, wg = dy.float().cuda(), w.float().cuda()
+        _lib.check(lib.cstp_conv3d_backward_data_acc(torch.cuda.current_stream().cuda_stream, ctypes.byref(desc), dyg.data_ptr(),
+                                                     wg.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), None, 1), "acc")
+        assert rel_err(dx - base, x.grad) < TOL                      # dx += gradient
+        _lib.check(lib.cstp_conv3d_backward_data_acc(torch.cuda.current_stream().cuda_stream, ctypes.byref(desc), dyg.data_ptr(),
+                                                     wg.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0), "set")
+        assert rel_err(dx, x.grad) < TOL                             # dx = gradient
+    finally:
+        ops.set_split_terms(0)
