@@ -19,6 +19,14 @@ for mt, st in ((4, 0), (8, 0), (9, 0), (4, 1), (8, 1), (9, 1)):
     sp = sum("scratch_" in l for l in body)
     print("igemm_k1p<%d, %s>: %d MFMA, scalar memory instructions among them: %d, scratch instructions: %d" % (mt, "true" if st else "false", len(idx), len(sl), sp))
     bad += sp
+# igemm_k2p (weight gradient, igemm_wpatch.h): 256 VGPRs are its whole budget -- a spilled accumulator shows up as scratch
+i = txt.index("_ZN4cstp9igemm_k2pE")
+body = txt[i:txt.index(".Lfunc_end", i)].split("\n")
+sp = sum("scratch_" in l for l in body)
+wf = sum("v_readfirstlane" in l for l in body)
+print("igemm_k2p: %d MFMA, %d transposing LDS reads, scratch instructions: %d, readfirstlane (waterfall loops around loads): %d"
+      % (sum("v_mfma" in l for l in body), sum("ds_read_b64_tr" in l for l in body), sp, wf))
+bad += sp + (1 if wf > 12 else 0)
 sys.exit(1 if bad else 0)
 PY
 rm -rf $tmp

@@ -2,7 +2,8 @@
 """Rehearse the N > 1 control flow of the pre-training step with the REAL HIP kernels on a one-GPU box: two ranks, both on
 cuda:0, process group over gloo (RCCL refuses two ranks on one device).  Everything of the multi-rank step runs except RCCL
 itself and the NT-Xent all-gather (gloo has no CUDA all_gather): tile-table broadcast, BN-buffer broadcast at the top of every
-step, forward/backward under no_sync(), ONE all-reduce of the flat gradient arena, clip, SGD, lagged log all-reduce.
+step, forward/backward under no_sync(), the gradient arena all-reduced in six slices started from backward hooks
+(train.StagedAllReduce), clip, SGD, lagged log all-reduce.
 Checks after each step: parameters and target parameters bit-identical across the ranks (the BN running statistics are per rank
 between two broadcasts, as under the reference's DDP); after the last step: sync_buffers (what validation / checkpointing call)
 makes the buffers identical too.
@@ -50,6 +51,11 @@ for it in range(steps):
     if rank == 0 and late is not None:
         print("  logged one step late:", late, flush=True)
     torch.cuda.synchronize()
+    if it == 0 and rank == 0:
+        red = step._reducer
+        print("gradient all-reduce: %d slices started from backward hooks (%s floats), the last one after backward"
+              % (len(red.slices), [n for _, n in red.slices]), flush=True)
+        assert len(red.slices) == 6 and red._next == 6 and sum(n for _, n in red.slices) == arenas["grad"].numel()
     flat = torch.cat([arenas["param"].detach().view(-1), arenas["target"].detach().view(-1)]).cpu()
     ref = flat.clone()
     dist.broadcast(ref, src=0)
