@@ -1178,6 +1178,9 @@ static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_ou
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    // developer knob: CSTP_PERSIST_CUS=<n> caps the persistent kernels' grids (leaves CUs to kernels of the other stream)
+    const char* e = getenv("CSTP_PERSIST_CUS");
+    if (e != nullptr && atoi(e) >= 8 && atoi(e) < n) n = atoi(e);
     return n > 8 ? n / 8 * 8 : 8;
   }();
   const long P = (long)d.n * d.d * d.h * d.w;
@@ -1193,6 +1196,8 @@ static int cu_count() {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("CSTP_PERSIST_CUS");
+    if (e != nullptr && atoi(e) >= 8 && atoi(e) < n) n = atoi(e);
     return n > 8 ? n / 8 * 8 : 8;
   }();
   return n_cu;
