@@ -371,7 +371,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     for (int e = t; e < 2 * BM * 2; e += 256) stat_s[e] = 0.0;       // (consumer threads are t < 256; read many barriers later)
   }
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
-  __builtin_amdgcn_s_setprio(2);                       // the matrix stream outranks the staging waves it shares SIMDs with
+#ifndef KP_PRIO
+#define KP_PRIO 2
+#endif
+  if (KP_PRIO > 0) __builtin_amdgcn_s_setprio(KP_PRIO);    // the matrix stream outranks the staging waves it shares SIMDs with
 
   // two instantiations of the body (the shared row tile's column range is a compile-time constant) instead of branches
   auto body = [&](auto xj0_tag, auto xjn_tag) __attribute__((always_inline)) {
