@@ -142,15 +142,25 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, float* _
   if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
 }
 
+__device__ __forceinline__ float key_to_float(unsigned k) {        // inverse of igemm_patch.h's key_of_float
+  return __builtin_bit_cast(float, (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 // ... the same for MANY partials per channel (the sums a convolution's persistent blocks left: up to 256 per channel and group):
 // one wave per channel, lanes stride over the partials
 __global__ void __launch_bounds__(64)
 bn_finalize_fwd_wide_kernel(const double* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_invstd,
                             float* __restrict__ running_mean, float* __restrict__ running_var, int c, int groups, int nsplit,
                             double count, float eps, float momentum, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell) {
+                            const float* __restrict__ beta, float2* __restrict__ ss, unsigned* __restrict__ cell,
+                            const unsigned* __restrict__ mm, int relu) {
   const int ch = blockIdx.x, lane = threadIdx.x;
-  if (ch == 0 && lane == 0 && cell != nullptr) *cell = 0;
+  // mm == null: the apply pass that follows measures its output, absmax_fold_kernel takes the maximum into the zeroed cell.
+  // mm != null (cstp_bn_finalize_pre): no apply pass follows -- the largest magnitude of act(x * scale + shift) comes from the
+  // channel's smallest and largest x (the map is monotone in x, and so is its fp32 rounding: the extreme outputs ARE the
+  // outputs of the extreme inputs), one atomicMax per channel into the cell the producing launch zeroed.
+  if (ch == 0 && lane == 0 && cell != nullptr && mm == nullptr) *cell = 0;
+  unsigned zmax = 0;
   float rm = 0.f, rv = 0.f;
   if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
   // the partials are sums of (x - pivot) and (x - pivot)^2; the pivot the producing launch used sits behind them
@@ -174,11 +184,33 @@ bn_finalize_fwd_wide_kernel(const double* __restrict__ part, float* __restrict__
         ss[g * c + ch] = make_float2(scl, beta[ch] - (float)mu * scl);
       }
     }
+    if (mm != nullptr) {
+      unsigned kmin = 0xffffffffu, kmax = 0u;
+      const unsigned* q = mm + ((size_t)ch * groups + g) * nsplit * 2;
+      for (int j = lane; j < nsplit; j += 64) {
+        const unsigned a = q[2 * j], b = q[2 * j + 1];
+        kmin = kmin < a ? kmin : a; kmax = kmax > b ? kmax : b;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)kmin, off, 64), b = (unsigned)__shfl_xor((int)kmax, off, 64);
+        kmin = kmin < a ? kmin : a; kmax = kmax > b ? kmax : b;
+      }
+      // the consumer's gather computes fma(x, scale, shift) with exactly these two table entries
+      const float scl = isf * gamma[ch];
+      const float sh = beta[ch] - (float)mu * scl;
+      float z0 = __builtin_fmaf(key_to_float(kmin), scl, sh), z1 = __builtin_fmaf(key_to_float(kmax), scl, sh);
+      if (relu) { z0 = fmaxf(z0, 0.f); z1 = fmaxf(z1, 0.f); }
+      const unsigned a0 = __builtin_bit_cast(unsigned, z0) & 0x7fffffffu, a1 = __builtin_bit_cast(unsigned, z1) & 0x7fffffffu;
+      const unsigned a = a0 > a1 ? a0 : a1;
+      zmax = zmax > a ? zmax : a;
+    }
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     rm = (float)((1.0 - momentum) * rm + momentum * mu);
     rv = (float)((1.0 - momentum) * rv + momentum * unb);
   }
   if (lane == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+  if (lane == 0 && mm != nullptr && cell != nullptr && zmax != 0) atomicMax(cell, zmax);
 }
 
 // ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
@@ -518,7 +550,7 @@ static int bn_forward_train_impl(void* stream, const float* x, const float* resi
     // the producing convolution left the sums (cstp_conv3d_forward_bnstats): no pass over x, a wave per channel folds them
     hipLaunchKernelGGL(bn_finalize_fwd_wide_kernel, dim3(c), dim3(64), 0, st, pre_part, save_mean, save_invstd, running_mean,
                        running_var, c, groups, pre_nsplit, (double)npg * s, eps, momentum, gamma, beta,
-                       reinterpret_cast<float2*>(scale_shift), y_absmax);
+                       reinterpret_cast<float2*>(scale_shift), y_absmax, nullptr, 0);
   } else {
     if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
     else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
@@ -538,6 +570,22 @@ static int bn_forward_train_impl(void* stream, const float* x, const float* resi
     hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, y_absmax);
     CSTP_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int cstp_bn_finalize_pre(void* stream, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float* save_mean, float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
+                                    int32_t groups, float eps, float momentum, int32_t relu, const double* part, int32_t nsplit,
+                                    uint32_t* z_cell) {
+  CSTP_REQUIRE(gamma && beta && save_mean && save_invstd && scale_shift && part && z_cell, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 1 && groups > 0 && (n % groups) == 0 && nsplit > 0, "bad shape");
+  CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
+  const int npg = n / groups;
+  const unsigned* mm = reinterpret_cast<const unsigned*>(part + (size_t)c * groups * nsplit * 2 + c);
+  hipLaunchKernelGGL(bn_finalize_fwd_wide_kernel, dim3(c), dim3(64), 0, as_stream(stream), part, save_mean, save_invstd,
+                     running_mean, running_var, c, groups, nsplit, (double)npg * s, eps, momentum, gamma, beta,
+                     reinterpret_cast<float2*>(scale_shift), z_cell, mm, relu);
+  CSTP_LAUNCH_CHECK();
   return 0;
 }
 

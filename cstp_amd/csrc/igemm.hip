@@ -1042,11 +1042,18 @@ static int pack_grid(size_t total) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-template <bool DGRAD, int NP>
+// optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h); npg = clips per BatchNorm group
+struct InAffine { const float2* ss; int npg, groups, relu; };
+
+template <bool DGRAD, int NP, bool AFF = false>
 static void launch_k1s_np(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const uint4* wps, const float* src,
-                          const float* bias, float* out, int ntx, int ntm, const float* inv_a, const unsigned* bcell) {
+                          const float* bias, float* out, int ntx, int ntm, const float* inv_a, const unsigned* bcell,
+                          const InAffine* ia = nullptr) {
+  const float2* aff_ss = AFF ? ia->ss : nullptr;
+  const int aff_gpos = AFF ? ia->npg * g.Dp * g.Hp * g.Wp : 1, aff_relu = AFF ? ia->relu : 0;
 #define CSTP_K1S(MT_, NH_) \
-  hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD, NH_, NP>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm, inv_a, bcell)
+  hipLaunchKernelGGL((igemm_k1s<MT_, DGRAD, NH_, NP, false, AFF>), grid, dim3(512), 0, s, g, wps, src, bias, out, ntx, ntm, inv_a, \
+                     bcell, aff_ss, aff_gpos, aff_relu)
   if (tl.wm == 2) {             // 256-column tiles: only the tall row tiles (registers: 16*MT*4 accumulators per lane)
     if (tl.mt == 8) CSTP_K1S(8, 2); else CSTP_K1S(9, 2);
     return;
@@ -1072,7 +1079,7 @@ static int absmax_grid(size_t n) {
 template <bool DGRAD>
 static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, const cstp_conv_desc& d, int ntaps, int Kp,
                     const float* w, const float* src, size_t src_elems, const float* bias, float* out, int ntx, int ntm,
-                    void* ws, size_t main_bytes, const uint32_t* src_absmax) {
+                    void* ws, size_t main_bytes, const uint32_t* src_absmax, const InAffine* ia = nullptr) {
   if (split_planes() == 3) {
     const size_t tot = (size_t)Kp * g.Mp;
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(pack_grid(tot / 2)), dim3(256), 0, s, w,
@@ -1084,6 +1091,12 @@ static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, con
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
   hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(g.Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
                      d.k, d.c, ntaps, g.Cp, g.Mp, Kp / 16, DGRAD ? 1 : 0);
+  if constexpr (!DGRAD) {
+    if (ia != nullptr && ia->ss != nullptr) {         // the gathered tensor is act(src * scale + shift); src_absmax is ITS maximum (checked by the caller)
+      launch_k1s_np<false, 2, true>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a, src_absmax, ia);
+      return;
+    }
+  }
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   launch_k1s_np<DGRAD, 2>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a,
                           src_absmax != nullptr ? src_absmax : cells);
@@ -1117,7 +1130,7 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
 #define CSTP_K1S_STR(MT_) \
   hipLaunchKernelGGL((igemm_k1s<MT_, false, 1, 2, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), xp, bias, \
-                     y, ntx, ntm, inv_a, cells)
+                     y, ntx, ntm, inv_a, cells, (const float2*)nullptr, 1, 0)
   if (tl.mt == 4) CSTP_K1S_STR(4); else if (tl.mt == 5) CSTP_K1S_STR(5); else CSTP_K1S_STR(6);
 #undef CSTP_K1S_STR
 }
@@ -1126,7 +1139,7 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
 // (forward: src = x, Cs = c, M = k;  data gradient: src = dy, Cs = k, M = c -- a 3x3 stride-1 convolution with mirrored taps)
 // BatchNorm partial sums as a by-product of a forward patch launch (igemm_k1p<MT, true>): possible when every 224-position tile
 // is full and lies inside one BN group, the output allows 16-byte stores, and a block meets one row block only
-struct K1pStats { double* part; int groups; const float* pivot; };
+struct K1pStats { double* part; int groups; const float* pivot; unsigned* zcell; };
 static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out);
 static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups) {
   if (tl.sp != 2 || groups < 1 || groups > 2 || d.n % groups != 0) return 0;
@@ -1164,10 +1177,11 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   dim3 grid((unsigned)(8 * slots), 1, 1);
   double* part = st ? st->part : nullptr;
   const float* pivot = st ? st->pivot : nullptr;
+  unsigned* zcell = st ? st->zcell : nullptr;
 #define CSTP_K1P(MT_) \
   do { \
-    if (part != nullptr) hipLaunchKernelGGL((igemm_k1p<MT_, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot); \
-    else hipLaunchKernelGGL((igemm_k1p<MT_, false>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot); \
+    if (part != nullptr) hipLaunchKernelGGL((igemm_k1p<MT_, true>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot, zcell); \
+    else hipLaunchKernelGGL((igemm_k1p<MT_, false>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot, zcell); \
   } while (0)
   if (tl.mt == 4) CSTP_K1P(4); else if (tl.mt == 8) CSTP_K1P(8); else CSTP_K1P(9);
 #undef CSTP_K1P
@@ -1229,8 +1243,6 @@ static int run_k2p(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, co
   return 0;
 }
 
-// optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h)
-struct InAffine { const float2* ss; int npg, groups, relu; };
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
   o.ss = nullptr; o.npg = 1; o.groups = 1; o.relu = 0;
   if (a == nullptr || a->scale_shift == nullptr) return 0;
@@ -1239,6 +1251,16 @@ static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InA
   o.ss = reinterpret_cast<const float2*>(a->scale_shift);
   o.groups = a->groups; o.npg = d.n / a->groups; o.relu = a->relu ? 1 : 0;
   return 0;
+}
+
+// Can a split (f16-pair gather) kernel apply the transform itself?  It needs the largest magnitude of the TRANSFORMED tensor
+// (absmax: the caller's cell, cstp_bn_finalize_pre), whole 16-channel groups, and column / K tiles (cols positions) that never
+// straddle two BatchNorm groups.
+static bool aff_split_ok(const cstp_conv_desc& d, const InAffine& ia, const uint32_t* absmax, long out_positions_per_clip, int cols) {
+  if (ia.ss == nullptr || absmax == nullptr || split_planes() != 2) return false;
+  if ((d.c & 15) != 0 || d.c > 1152 || ia.groups > 2) return false;      // (1152: the kernels' LDS tables)
+  const long gpos = (long)ia.npg * out_positions_per_clip;
+  return gpos % cols == 0 && gpos < (1l << 30);
 }
 
 }  // namespace cstp
@@ -1257,6 +1279,18 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
   return cstp_conv3d_forward_am(stream, desc, x, w, bias, in_affine, y, ws, ws_bytes, nullptr);
 }
 
+extern "C" int32_t cstp_conv3d_in_affine_fused(const cstp_conv_desc* desc, int32_t groups) {
+  ConvPlan p;
+  if (desc == nullptr || !make_plan(*desc, p) || groups < 1 || desc->n % groups != 0) return 0;
+  const cstp_conv_desc& d = *desc;
+  InAffine ia{reinterpret_cast<const float2*>(desc), d.n / groups, groups, 1};       // (ss: any non-null pointer, never read here)
+  const uint32_t* some = reinterpret_cast<const uint32_t*>(desc);
+  const long S = (long)p.Do * p.Ho * p.Wo;
+  const bool fwd = p.f_t.sp == 1 && !p.f_straddle && aff_split_ok(d, ia, some, S, tile_bn(p.f_t));
+  const bool wgr = p.w_split && !p.w_straddle && !p.w_patch && aff_split_ok(d, ia, some, S, 32);
+  return fwd && wgr ? 1 : 0;
+}
+
 extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups) {
   ConvPlan p;
   if (desc == nullptr || !make_plan(*desc, p)) return 0;
@@ -1265,7 +1299,7 @@ extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_
 
 extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y,
                                            void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot,
-                                           double* part, size_t part_bytes, int32_t* nsplit_out) {
+                                           double* part, size_t part_bytes, int32_t* nsplit_out, uint32_t* z_cell) {
   CSTP_REQUIRE(desc && x && w && y && ws && part && nsplit_out, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
@@ -1274,11 +1308,11 @@ extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* d
   if (ns == 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)       // this layer's kernel cannot deliver the sums: plain forward
     return cstp_conv3d_forward_am(stream, desc, x, w, nullptr, nullptr, y, ws, ws_bytes, x_absmax);
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
-  CSTP_REQUIRE(part_bytes >= ((size_t)desc->k * groups * ns * 2 + desc->k) * sizeof(double), "partial-sum buffer too small");
+  CSTP_REQUIRE(part_bytes >= ((size_t)desc->k * groups * ns * 3 + desc->k) * sizeof(double), "partial-sum buffer too small");
   const cstp_conv_desc& d = *desc;
   CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
-  const K1pStats st{part, groups, pivot};
+  const K1pStats st{part, groups, pivot, z_cell};
   run_k1p(p.f_t, as_stream(stream), d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, &st);
   CSTP_LAUNCH_CHECK();
   *nsplit_out = ns;
@@ -1297,8 +1331,13 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
-  if (p.f_t.sp != 0 && in_affine != nullptr && in_affine->scale_shift != nullptr) {
-    // the split kernel has no fused input transform: such a call runs a native tile (and its operand padding)
+  InAffine ia;
+  if (parse_in_affine(in_affine, d, ia)) return 1;
+  // the fused input transform on the f16-pair gather kernel (igemm_k1s<.., AFF>): see aff_split_ok
+  const bool aff_split = ia.ss != nullptr && p.f_t.sp == 1 && !p.f_straddle &&
+                         aff_split_ok(d, ia, x_absmax, (long)p.Do * p.Ho * p.Wo, tile_bn(p.f_t));
+  if (p.f_t.sp != 0 && ia.ss != nullptr && !aff_split) {
+    // no fused input transform on this layer's split kernel: such a call runs a native tile (and its operand padding)
     p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
     if (p.f_t.sp) p.f_t = Tile{2, 1, 0, 1, 0};
     p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
@@ -1332,10 +1371,8 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
   const int f_bm = tile_bm(p.f_t), f_bn = tile_bn(p.f_t);
   const int ntx = cdiv(npos, f_bn), ntm = cdiv(d.k, f_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), 1, 1);
-  InAffine ia;
-  if (parse_in_affine(in_affine, d, ia)) return 1;
   if (f_split) run_k1s<false>(p.f_t, grid, s, g, d, p.ntaps, p.f_Kp, w, x, (size_t)d.n * d.c * d.d * d.h * d.w, bias, y, ntx, ntm,
-                              ws, plan_main_bytes(d, p), x_absmax);
+                              ws, plan_main_bytes(d, p), x_absmax, aff_split ? &ia : nullptr);
   else if (p.f_straddle) launch_k1<false, true, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
   else if (ia.ss) launch_k1<false, false, true>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, ia.ss, ia.npg, ia.relu);
   else launch_k1<false, false, false>(p.f_t, grid, s, g, wp, x, bias, y, ntx, ntm, nullptr, 1, 0);
@@ -1458,8 +1495,10 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
     CSTP_LAUNCH_CHECK();
     return 0;
   }
-  // the split kernel has no fused input transform: a call that carries one runs the native kernel with its analytic tile
-  const bool w_split = p.w_split && ia.ss == nullptr;
+  // the fused input transform: on the f16-pair gather kernel (igemm_k2s<.., AFF>) where aff_split_ok, else the native kernel
+  // with its analytic tile
+  const bool aff_split = ia.ss != nullptr && p.w_split && !p.w_straddle && aff_split_ok(d, ia, x_absmax, (long)p.Do * p.Ho * p.Wo, 32);
+  const bool w_split = p.w_split && (ia.ss == nullptr || aff_split);
   if (p.w_split && !w_split) p.w_mt = (CSTP_M16 && d.k > 128 && d.k <= 144) ? 9 : pick_mt(d.k);
   const int npos = d.n * p.Do * p.Ho * p.Wo;
   const int bkn = CSTP_K2_BKN;
@@ -1495,7 +1534,7 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
     Geom gs = g;
     gs.Ds = Dq; gs.Hs = Hq; gs.Ws = Wq; gs.pt = 0; gs.ph = 0; gs.pw = 0; gs.Cp = d.c;
 #define CSTP_K2S_STR(MT_) \
-  hipLaunchKernelGGL((igemm_k2s<MT_, 2, true>), grid, dim3(512), 0, s, gs, dy, xp, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, cells, dycell, det_stride)
+  hipLaunchKernelGGL((igemm_k2s<MT_, 2, true>), grid, dim3(512), 0, s, gs, dy, xp, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, cells, dycell, det_stride, (const float2*)nullptr, 1, 1, 0)
     if (p.w_mt == 9) CSTP_K2S_STR(9); else if (p.w_mt == 4) CSTP_K2S_STR(4); else CSTP_K2S_STR(8);
 #undef CSTP_K2S_STR
     CSTP_LAUNCH_CHECK();
@@ -1507,16 +1546,20 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
   }
   if (w_split) {
 #define CSTP_K2S(MT_, NP_) \
-  hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell, det_stride)
+  hipLaunchKernelGGL((igemm_k2s<MT_, NP_>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell, det_stride, (const float2*)nullptr, 1, 1, 0)
+#define CSTP_K2S_AFF(MT_) \
+  hipLaunchKernelGGL((igemm_k2s<MT_, 2, false, true>), grid, dim3(512), 0, s, g, dy, x, dwp, p.w_Jtot, p.w_Jp, kt_total, kt_per, ntm, ntj, splits, xcell, dycell, det_stride, ia.ss, ia.npg * p.Do * p.Ho * p.Wo, ia.groups, ia.relu)
     if (w_f16) {
       const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
       if (x_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(nx)), dim3(256), 0, s, x, nx, cells);
       if (dy_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s, dy, ny, cells + 1);
-      if (p.w_mt == 9) CSTP_K2S(9, 2); else if (p.w_mt == 4) CSTP_K2S(4, 2); else CSTP_K2S(8, 2);
+      if (aff_split) { if (p.w_mt == 9) CSTP_K2S_AFF(9); else if (p.w_mt == 4) CSTP_K2S_AFF(4); else CSTP_K2S_AFF(8); }
+      else if (p.w_mt == 9) CSTP_K2S(9, 2); else if (p.w_mt == 4) CSTP_K2S(4, 2); else CSTP_K2S(8, 2);
     } else {
       if (p.w_mt == 9) CSTP_K2S(9, 3); else if (p.w_mt == 4) CSTP_K2S(4, 3); else CSTP_K2S(8, 3);
     }
 #undef CSTP_K2S
+#undef CSTP_K2S_AFF
   } else if (p.w_straddle) {
     if (v4) launch_k2<true, true, CSTP_K2_BKN, false>(CSTP_K2_ARGS);
     else launch_k2<true, false, CSTP_K2_BKN, false>(CSTP_K2_ARGS);

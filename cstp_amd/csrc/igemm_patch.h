@@ -115,11 +115,23 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
 // magnitude, and var = E[(y-c)^2] - (E[y-c])^2 no longer cancels for channels with |mean| >> std (round-2 ADVICE).  A lane of
 // the transposed accumulator tile holds 28 values of ONE channel, so the per-item work is 2 FMAs per value, two cross-row adds
 // and one fp64 LDS atomic per lane-channel; the block keeps its sums in LDS across its items and writes them once at the end.
+// Next to the sums the launch leaves each channel's SMALLEST and LARGEST output per group (ordered-integer keys of the fp32
+// values, key_of_float, behind the pivots: mm[((ch * groups + grp) * nsplit + j) * 2 + {min, max}]): with them the BatchNorm
+// finalize knows the exact range of relu(scale * y + shift) -- the operand scale of the convolution that consumes the
+// normalised tensor WITHOUT that tensor ever being written (cstp_bn_finalize_pre, in_affine of the temporal convolution).
+__device__ __forceinline__ unsigned key_of_float(float f) {
+  const unsigned b = __builtin_bit_cast(unsigned, f);
+  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);           // monotone: a < b  <=>  key(a) < key(b)
+}
+__device__ __forceinline__ float float_of_key(unsigned k) {
+  return __builtin_bit_cast(float, (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 template <int MT, bool STATS = false>
 __global__ void __launch_bounds__(512, 2)
 igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict__ src, float* __restrict__ out,
           const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk, double* __restrict__ part,
-          const float* __restrict__ pivot) {
+          const float* __restrict__ pivot, unsigned* __restrict__ zcell) {
   constexpr int BM = 16 * MT;
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
@@ -159,6 +171,18 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       }
     }
   };
+  // STATS: my slots of the minimum / maximum table start neutral; the consumers' atomics (many barriers later) shrink / grow them
+  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
+  if constexpr (STATS) {
+    for (int e = threadIdx.x; e < g.groups * BM; e += 512) {
+      const int row = e % BM, grp = e / BM, ch = st_mblk * BM + row;
+      if (ch < g.M)
+        *reinterpret_cast<uint2*>(mmk + (((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2) = make_uint2(0xffffffffu, 0u);
+    }
+    // the cell the BatchNorm finalize takes the consumer's operand maximum into (atomicMax): zeroed here, a launch earlier
+    if (blockIdx.x == 0 && threadIdx.x == 0 && zcell != nullptr) *zcell = 0;
+    __threadfence();
+  }
   if (nitems == 0) {
     if constexpr (STATS) { if (threadIdx.x < 256) write_part(true); }
     return;
@@ -592,6 +616,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         const int m = mblk * BM + mrow;
         float* orow = out + (size_t)m * chs;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        float vmin = __builtin_inff(), vmax = -__builtin_inff();      // STATS: smallest / largest accumulator of my channel
         float pv = 0.f;                                  // STATS: the pivot in accumulator units (y = v * sc)
         if constexpr (STATS) { if (pivot != nullptr && m < g.M) pv = pivot[m] / sc; }
 #pragma unroll
@@ -602,7 +627,11 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
             f32x4* dst = reinterpret_cast<f32x4*>(orow + obase[j]);
             *dst = g.acc ? *dst + v * sc : v * sc;
           }
-          if constexpr (STATS) { const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv; }     // (every position of every tile is valid: host condition)
+          if constexpr (STATS) {                           // (every position of every tile is valid: host condition)
+            const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv;
+            vmin = __builtin_fminf(__builtin_fminf(vmin, v[0]), v[1]); vmin = __builtin_fminf(__builtin_fminf(vmin, v[2]), v[3]);
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, v[0]), v[1]); vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, v[2]), v[3]);
+          }
         }
         if constexpr (STATS) {
           // my channel's 28 (or 16 / 12) values -> the four lanes that share it (lane, lane ^ 16, ^ 32, ^ 48) -> LDS
@@ -613,6 +642,14 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
             double* dst = stat_s + (st_grp * BM + mrow) * 2;
             __hip_atomic_fetch_add(dst, (double)(a * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(dst + 1, (double)(b * sc) * (double)sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          // the range: sc > 0 and rounding is monotone, so min(v) * sc IS the smallest stored output
+          vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 16, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 16, 64));
+          vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 32, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+          if (q == 0 && m < g.M) {
+            unsigned* mm = mmk + (((size_t)m * g.groups + st_grp) * st_nsplit + st_j) * 2;
+            atomicMin(mm, key_of_float(vmin * sc));
+            atomicMax(mm + 1, key_of_float(vmax * sc));
           }
         }
       }

@@ -76,8 +76,24 @@ __device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, fl
   inv = __builtin_bit_cast(float, (unsigned)(127 - sh) << 23);
 }
 
-// two fp32 (times the operand scale) -> two packed f16 pairs
+// two fp32 (times the operand scale) -> two packed f16 pairs:  h = f16(x * sc),  l = f16(x * sc - h)  (both roundings to nearest
+// even; x * sc and the difference are exact in fp32).  FOUR instructions per pair of elements: the mixed-precision FMAs take the
+// f16 halves of h as their addend directly and write an f16 half of the result register (v_fma_mixlo/hi_f16: fp32 FMA, then
+// the conversion), where the generic form spends six (packed multiply, packed convert, two f16 -> f32 conversions, packed
+// subtract, packed convert) -- the split is most of the vector-ALU work of every gather / staging wave of the split kernels.
+#ifndef CSTP_SPLIT_MIX
+#define CSTP_SPLIT_MIX 1
+#endif
 __device__ __forceinline__ void split2h(float x0, float x1, float sc, unsigned& h, unsigned& l) {
+#if CSTP_SPLIT_MIX
+  unsigned hh, ll;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=&v"(hh) : "v"(x0), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(hh) : "v"(x1), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(ll) : "v"(x0), "v"(sc), "v"(hh));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(sc), "v"(hh));
+  h = hh;
+  l = ll;
+#else
   f32x2 v = {x0, x1};
   v = v * sc;
   const f16x2 hh = __builtin_convertvector(v, f16x2);
@@ -85,6 +101,7 @@ __device__ __forceinline__ void split2h(float x0, float x1, float sc, unsigned& 
   const f16x2 ll = __builtin_convertvector(r, f16x2);
   h = __builtin_bit_cast(unsigned, hh);
   l = __builtin_bit_cast(unsigned, ll);
+#endif
 }
 
 // largest magnitude of a tensor, as fp32 bits with the sign cleared (a NaN compares above everything and propagates)
@@ -259,12 +276,20 @@ pad_input_kernel(const float* __restrict__ x, float* __restrict__ xp, unsigned* 
 
 constexpr int STR_KMAX = 1056;                       // table entries: 7x7x7 taps x 3 channels = 1029, padded to 16
 
-template <int MT, bool DGRAD, int NH, int NP, bool STR = false>
+// AFF (forward, f16 pair): the gathered tensor is z = act(src * scale + shift) with one (scale, shift) pair per (BatchNorm group,
+// channel) -- the train-mode BatchNorm + ReLU in front of the temporal convolution (r21d_byol.py:94-97) applied to the raw
+// operands between their load and their split, so z never exists in HBM.  The 16 channels of a producer's group are
+// wave-uniform: their pairs arrive through scalar loads.  A halo / padding position is an out-of-range load (0) and must
+// STAY 0 (zero padding applies to z): the clamp that implements the ReLU, med3(v, 0, cap), has cap = 0 at such positions.
+// Host conditions: Cs a multiple of 16, no column tile straddles two BatchNorm groups (aff_gpos positions per group, a
+// multiple of the tile's columns); *bcell is the largest magnitude of z (cstp_bn_finalize_pre).
+template <int MT, bool DGRAD, int NH, int NP, bool STR = false, bool AFF = false>
 __global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 4 : 1)      // the f16-pair 128-column tiles: two blocks per CU (<= 128 VGPRs)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
-          const unsigned* __restrict__ bcell) {
+          const unsigned* __restrict__ bcell, const float2* __restrict__ aff_ss, int aff_gpos, int aff_relu) {
   static_assert(NP == 2 || NP == 3, "planes per operand");
+  static_assert(!AFF || (NP == 2 && !DGRAD && !STR), "the fused input transform serves the f16-pair forward gather");
   constexpr int BM = 16 * MT, BN = 128 * NH;
   constexpr int NC = 2 * NH;                         // 16-column tiles per consumer wave
   constexpr int ACPR = 2 * NP;                       // 16-byte chunks per A row and 16-k group
@@ -279,6 +304,8 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     return NP == 2 ? ((plane * 4 + c) ^ (row & 7)) : (plane * 4 + (c ^ spl_swz(row)));
   };
   static_assert(!STR || (!DGRAD && NH == 1), "the straddle mode serves the forward 128-column tiles");
+  constexpr int AFF_MAXC = 1152;                    // AFF: channels of the gathered tensor (host-checked)
+  __shared__ __attribute__((aligned(16))) float aff_a[AFF ? AFF_MAXC : 4], aff_b[AFF ? AFF_MAXC : 4];   // scale / shift per channel
   __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
   __shared__ __attribute__((aligned(16))) unsigned ktab[STR ? STR_KMAX : 4];   // STR: byte offset of reduction index k
   __shared__ __attribute__((aligned(16))) float inva_s[NP == 2 ? BM : 4];   // NP == 2: inverse row scales of this row tile
@@ -312,6 +339,13 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 
   const int khw = g.kh * g.kw, ntaps = g.kt * khw;
   const int gpt = g.Cp >> 4;                         // 16-channel groups per tap
+
+  if constexpr (AFF) {
+    // my tile's BatchNorm group (uniform): its table goes to LDS once, the producers read it at every split
+    const float2* ssg = aff_ss + (size_t)(n0 / aff_gpos) * g.Cs;
+    for (int c = t; c < g.Cs; c += 512) { const float2 p = ssg[c]; aff_a[c] = p.x; aff_b[c] = p.y; }
+    __syncthreads();
+  }
 
   // ---- the tap sequence (block-uniform)
   int nvt = ntaps;
@@ -431,10 +465,18 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 
     u32x4 ra0[A_IT], ra1[A_IT];
     float rb0[NH][16], rb1[NH][16];
+    // AFF: what a register set needs at split time -- its channel block and, per position, the clamp's upper end
+    struct AffSet { int cg; float cap[NH]; };
+    AffSet as0 = {}, as1 = {};
 
     // issue the loads of my current group into the given register set, then advance to my next group
-    auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
+    auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16], AffSet& as) __attribute__((always_inline)) {
       const bool have = e < ngroups;                  // uniform; a missing group loads zeros (OOB offsets)
+      if constexpr (AFF) {
+        as.cg = cg;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) as.cap[h] = vb0[h] != OOB ? __builtin_inff() : 0.f;
+      }
       const unsigned sa = (unsigned)(((size_t)(STR ? e : tap * gpt + cg) * g.Mp + m0) * (32 * NP));
       const unsigned vfull = have ? va_full : OOB, vlast = have ? va_last : OOB;
 #pragma unroll
@@ -469,10 +511,34 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       }
     };
 
-    auto split_store = [&](int buf, u32x4 (&ra)[A_IT], float (&rb)[NH][16]) __attribute__((always_inline)) {
+    auto split_store = [&](int buf, u32x4 (&ra)[A_IT], float (&rb)[NH][16], const AffSet& as) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < A_IT; ++j)
         if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
+      if constexpr (AFF) {
+        // the group's 16 scales and 16 shifts: same LDS address in every lane (broadcast reads), pairs of channels in adjacent
+        // registers -- one packed FMA per two elements, one clamp per element
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4* ta = reinterpret_cast<const f32x4*>(aff_a + (as.cg << 4));
+        const f32x4* tb = reinterpret_cast<const f32x4*>(aff_b + (as.cg << 4));
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const f32x4 a4 = ta[j4], b4 = tb[j4];
+#pragma unroll
+          for (int jj = 0; jj < 4; jj += 2) {
+            const int j = 4 * j4 + jj;
+            const f32x2 a2 = {a4[jj], a4[jj + 1]}, b2 = {b4[jj], b4[jj + 1]};
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+              const f32x2 v2 = {rb[h][j], rb[h][j + 1]};
+              const f32x2 z2 = __builtin_elementwise_fma(v2, a2, b2);
+              const float lo = aff_relu ? 0.f : -as.cap[h];
+              rb[h][j] = __builtin_amdgcn_fmed3f(z2[0], lo, as.cap[h]);
+              rb[h][j + 1] = __builtin_amdgcn_fmed3f(z2[1], lo, as.cap[h]);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         uint4* brow = &Bs[buf][b_lds + 128 * h * ROWC];
@@ -510,39 +576,39 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     return;
 #endif
     if (ntiles >= 4) {
-      issue_loads(ra0, rb0);                          // tile 0
-      issue_loads(ra1, rb1);                          // tile 1
-      split_store(0, ra0, rb0);
-      issue_loads(ra0, rb0);                          // tile 2
+      issue_loads(ra0, rb0, as0);                     // tile 0
+      issue_loads(ra1, rb1, as1);                     // tile 1
+      split_store(0, ra0, rb0, as0);
+      issue_loads(ra0, rb0, as0);                     // tile 2
       __syncthreads();
       while (i + 4 < ntiles) {
-        split_store(1, ra1, rb1);                     // tile i+1
-        issue_loads(ra1, rb1);                        // tile i+3
+        split_store(1, ra1, rb1, as1);                // tile i+1
+        issue_loads(ra1, rb1, as1);                   // tile i+3
         __syncthreads();
-        split_store(0, ra0, rb0);                     // tile i+2
-        issue_loads(ra0, rb0);                        // tile i+4
+        split_store(0, ra0, rb0, as0);                // tile i+2
+        issue_loads(ra0, rb0, as0);                   // tile i+4
         __syncthreads();
         i += 2;
       }
     } else {
-      if (ntiles > 0) issue_loads(ra0, rb0);
-      if (ntiles > 1) issue_loads(ra1, rb1);
+      if (ntiles > 0) issue_loads(ra0, rb0, as0);
+      if (ntiles > 1) issue_loads(ra1, rb1, as1);
       if (ntiles > 0) {
-        split_store(0, ra0, rb0);
-        if (ntiles > 2) issue_loads(ra0, rb0);
+        split_store(0, ra0, rb0, as0);
+        if (ntiles > 2) issue_loads(ra0, rb0, as0);
       }
       __syncthreads();
     }
     for (; i < ntiles; i += 2) {                      // tail (and the whole loop of short reductions)
       if (i + 1 < ntiles) {                           // stage tile i+1 (set 1) while tile i is consumed
-        split_store(1, ra1, rb1);
-        if (i + 3 < ntiles) issue_loads(ra1, rb1);
+        split_store(1, ra1, rb1, as1);
+        if (i + 3 < ntiles) issue_loads(ra1, rb1, as1);
       }
       __syncthreads();
       if (i + 1 >= ntiles) break;
       if (i + 2 < ntiles) {                           // stage tile i+2 (set 0) while tile i+1 is consumed
-        split_store(0, ra0, rb0);
-        if (i + 4 < ntiles) issue_loads(ra0, rb0);
+        split_store(0, ra0, rb0, as0);
+        if (i + 4 < ntiles) issue_loads(ra0, rb0, as0);
       }
       __syncthreads();
     }
@@ -716,13 +782,21 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 // STR (NP == 2 only): layers with fewer than 8 input channels (the 3-channel stems).  The columns run j = tap * Cs + c with NO
 // channel padding (147 columns for the 1x7x7 stem instead of 49 taps x 32), the source is the ZERO-PADDED copy of x
 // (pad_input_kernel), and each of a producer's 16 columns has its own constant offset from the position's base.
-template <int MT, int NP, bool STR = false>
+// AFF (NP == 2): x stands for z = act(x * scale + shift), the BatchNorm + ReLU in front of the convolution recomputed in this
+// gather exactly as igemm_k1s<.., AFF> applied it in the forward pass (*xcell = largest magnitude of z).  A K-tile's 32
+// positions lie in one BatchNorm group (aff_gpos positions per group, a multiple of 32: host condition); the (scale, shift)
+// pairs of the block's 128 columns sit in LDS for every group and a producer reads its 16 pairs per tile (same address across
+// its 32 lanes: broadcast).
+template <int MT, int NP, bool STR = false, bool AFF = false>
 __global__ void __launch_bounds__(512, NP == 2 ? 4 : 1)      // f16 pair: the LDS images fit twice into a CU (4 waves per SIMD: <= 128 VGPRs)
 igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp, int Jtot, int Jp,
           int ktiles_total, int ktiles_per_split, int ntm, int ntj, int nsplit, const unsigned* __restrict__ xcell,
-          const unsigned* __restrict__ dycell, size_t det_stride) {
+          const unsigned* __restrict__ dycell, size_t det_stride, const float2* __restrict__ aff_ss, int aff_gpos, int aff_groups,
+          int aff_relu) {
   static_assert(MT == 4 || MT == 8 || MT == 9, "row tiles: 64 or 128 main rows (+16)");
   static_assert(NP == 2 || NP == 3, "planes per operand");
+  static_assert(!AFF || (NP == 2 && !STR), "the fused input transform serves the f16-pair gather");
+  __shared__ __attribute__((aligned(16))) float aff_a[AFF ? 2 * 128 : 4], aff_b[AFF ? 2 * 128 : 4];   // scale / shift [group (<= 2)][column of this block]
   constexpr int BM = 16 * MT, BJ = 128;
   constexpr bool XTRA = MT == 9;
   constexpr int AP = MT == 4 ? 16 : 32;              // 8-byte pieces per k-row of the dY image (64 / 128 columns)
@@ -759,6 +833,19 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
   auto prow = [](int r) __attribute__((always_inline)) -> int {
     return (r & 3) | (((r >> 3) & 1) << 2) | (((r >> 2) & 1) << 3) | (r & 16);
   };
+
+  if constexpr (AFF) {
+    // column j0 + col = (tap, channel), clamped as the producers' offsets below are
+    if (t < aff_groups * 128) {
+      const int grp = t >> 7, col = t & 127;
+      const int jg = j0 + col;
+      int c = jg - (jg / g.Cp) * g.Cp;
+      c = c < g.Cs ? c : g.Cs - 1;
+      const float2 p = aff_ss[grp * g.Cs + c];
+      aff_a[t] = p.x; aff_b[t] = p.y;
+    }
+    __syncthreads();
+  }
 
   if (wave >= 4) {
     // ================================================= producers =================================================
@@ -821,6 +908,8 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
     const int x_slot = prow(r) * 4 + (q >> 1);       // extra image: piece q>>1, dword q&1
 
     float ra0[AR], rb0[16], rx0[2], ra1[AR], rb1[16], rx1[2];
+    struct AffSet { int tab; float cap; };            // AFF: first table entry of the tile's group; the clamp's upper end
+    AffSet as0 = {}, as1 = {};
     float sc_x = 1.f, sc_dy = 1.f;                    // NP == 2: operand scales
     if (NP == 2) {
       float inv_unused;
@@ -828,7 +917,7 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       f16_scale(__builtin_amdgcn_readfirstlane(*dycell), sc_dy, inv_unused);
     }
 
-    auto issue_loads = [&](int i, float (&ra)[AR], float (&rb)[16], float (&rx)[2]) __attribute__((always_inline)) {
+    auto issue_loads = [&](int i, float (&ra)[AR], float (&rb)[16], float (&rx)[2], AffSet& as) __attribute__((always_inline)) {
       const int n = (kt_begin + i) * 32 + r;
       const bool valid = n < n_end;
       const int nn = valid ? n : 0;
@@ -839,6 +928,12 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
       const int id = d * g.st - g.pt + dt, ih = h * g.sh - g.ph + dh, iw = w * g.sw - g.pw + dw;
       const bool okx = valid && (unsigned)id < (unsigned)g.Ds && (unsigned)ih < (unsigned)g.Hs && (unsigned)iw < (unsigned)g.Ws;
       const unsigned base_x = okx ? ((unsigned)b * (unsigned)g.Cs * (unsigned)DHWs + (unsigned)(id * HWs + ih * g.Ws + iw)) * 4u : OOB;
+      if constexpr (AFF) {
+        int grp = ((kt_begin + i) * 32) / aff_gpos;   // uniform; tiles past the end of the tensor read zeros whatever the group
+        grp = grp < aff_groups ? grp : aff_groups - 1;
+        as.tab = grp * 128 + 16 * q;
+        as.cap = okx ? __builtin_inff() : 0.f;
+      }
 #pragma unroll
       for (int j = 0; j < AR; ++j)
         ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, base_dy + moff[j], 0, 0));
@@ -903,9 +998,27 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
         *reinterpret_cast<uint4*>(img[NP - 1] + (slot & ~1)) = pl;
       }
     };
-    auto split_store = [&](int buf, const float (&ra)[AR], const float (&rb)[16], const float (&rx)[2]) __attribute__((always_inline)) {
+    auto split_store = [&](int buf, const float (&ra)[AR], float (&rb)[16], const float (&rx)[2], const AffSet& as) __attribute__((always_inline)) {
       if constexpr (AR == 16) store16(Am[buf], a_slot, reinterpret_cast<const float(&)[16]>(ra), sc_dy);
       else store8(Am[buf], a8_slot, ra, sc_dy);
+      if constexpr (AFF) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float lo = aff_relu ? 0.f : -as.cap;
+        const f32x4* ta = reinterpret_cast<const f32x4*>(aff_a + as.tab);
+        const f32x4* tb = reinterpret_cast<const f32x4*>(aff_b + as.tab);
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const f32x4 a4 = ta[j4], b4 = tb[j4];         // scales / shifts of channels 4 j4 .. 4 j4 + 3 (two lane groups, two addresses)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj += 2) {
+            const int j = 4 * j4 + jj;
+            const f32x2 v2 = {rb[j], rb[j + 1]}, a2 = {a4[jj], a4[jj + 1]}, b2 = {b4[jj], b4[jj + 1]};
+            const f32x2 z2 = __builtin_elementwise_fma(v2, a2, b2);
+            rb[j] = __builtin_amdgcn_fmed3f(z2[0], lo, as.cap);
+            rb[j + 1] = __builtin_amdgcn_fmed3f(z2[1], lo, as.cap);
+          }
+        }
+      }
       store16(Bm[buf], a_slot, rb, sc_x);
       if (XTRA) {
         if constexpr (NP == 2) {
@@ -925,18 +1038,18 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
 
     // No load is conditional (tiles past the end of the split read zeros through OOB offsets): the compiler's counted
     // s_waitcnt keeps two K-tiles in flight (see igemm_k1s).
-    issue_loads(0, ra0, rb0, rx0);
-    issue_loads(1, ra1, rb1, rx1);
-    split_store(0, ra0, rb0, rx0);
-    issue_loads(2, ra0, rb0, rx0);
+    issue_loads(0, ra0, rb0, rx0, as0);
+    issue_loads(1, ra1, rb1, rx1, as1);
+    split_store(0, ra0, rb0, rx0, as0);
+    issue_loads(2, ra0, rb0, rx0, as0);
     __syncthreads();
     for (int i = 0; i < ntiles; i += 2) {
-      split_store(1, ra1, rb1, rx1);                  // tile i+1
-      issue_loads(i + 3, ra1, rb1, rx1);
+      split_store(1, ra1, rb1, rx1, as1);             // tile i+1
+      issue_loads(i + 3, ra1, rb1, rx1, as1);
       __syncthreads();
       if (i + 1 >= ntiles) break;
-      split_store(0, ra0, rb0, rx0);                  // tile i+2
-      issue_loads(i + 4, ra0, rb0, rx0);
+      split_store(0, ra0, rb0, rx0, as0);             // tile i+2
+      issue_loads(i + 4, ra0, rb0, rx0, as0);
       __syncthreads();
     }
     return;

@@ -386,16 +386,19 @@ class _Conv3d(torch.autograd.Function):
         _Conv3d._last_stats = None
         with _span("conv3d_forward", lambda: _desc_key(desc)):
             if ns > 0:
-                part = torch.empty(w.shape[0] * bn_groups * ns * 2 + w.shape[0], dtype=torch.float64, device=x.device)
+                # sums [k][groups][ns][2], pivots [k], then the (min, max) keys [k][groups][ns][2] as uint32 (one double each)
+                part = torch.empty(w.shape[0] * bn_groups * ns * 3 + w.shape[0], dtype=torch.float64, device=x.device)
+                zcell = torch.empty(1, dtype=torch.int32, device=x.device)
                 got = ctypes.c_int32(0)
                 pv = None if bn_pivot is None else _req(bn_pivot, "BatchNorm pivot")
                 if pv is not None and pv.numel() != w.shape[0]:
                     raise _lib.CstpError("BatchNorm pivot has %d entries for %d output channels" % (pv.numel(), w.shape[0]))
                 check(lib.cstp_conv3d_forward_bnstats(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), _ptr(xam), bn_groups, _ptr(pv), part.data_ptr(),
-                                                      part.numel() * 8, ctypes.byref(got)), "cstp_conv3d_forward_bnstats")
+                                                      part.numel() * 8, ctypes.byref(got), zcell.data_ptr()),
+                      "cstp_conv3d_forward_bnstats")
                 if got.value > 0:
-                    _Conv3d._last_stats = (part, got.value, bn_groups)
+                    _Conv3d._last_stats = (part, got.value, bn_groups, zcell)
             else:
                 check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None,
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
@@ -493,9 +496,10 @@ def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None, gra
 
 
 def _bnstats_of(t, groups):
+    """(partials, nsplit, cell) the convolution that produced ``t`` left for a BatchNorm over ``groups`` groups, or None."""
     tag = getattr(t, "_cstp_bnstats", None)
-    if tag is not None and tag[3] == t._version and tag[2] == groups and tag[0].device == t.device:
-        return tag[0], tag[1]
+    if tag is not None and tag[4] == t._version and tag[2] == groups and tag[0].device == t.device:
+        return tag[0], tag[1], tag[3]
     return None
 
 
@@ -634,13 +638,19 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, residual=None, re
 # fused  BatchNorm(train) -> ReLU -> conv3d : the normalised tensor never exists in HBM
 # ----------------------------------------------------------------------------------------------
 class _BNReluConv3d(torch.autograd.Function):
-    """y = conv3d(relu(batch_norm_train(x)), w).  Forward: one statistics pass over x, then the convolution
-    applies x*scale+shift (+ReLU) inside its gather.  Backward: data gradient of the convolution, weight gradient
-    with the same transform recomputed in ITS gather, then the BN backward with the ReLU mask recomputed from x."""
+    """y = conv3d(relu(batch_norm_train(x)), w) (r21d_byol.py:94-97: temporal_conv(relu(bn(spatial_conv(.))))).
+    Forward: the statistics (folded from the partial sums the producing convolution left, else one pass over x), then the
+    convolution applies x*scale+shift (+ReLU) inside its gather.  Backward: weight gradient with the same transform
+    recomputed in ITS gather (side stream, straight into the gradient arena), data gradient of the convolution, then the
+    BN backward with the ReLU mask recomputed from x."""
+    _pre_stats = None     # (partials, nsplit, cell) of the producing convolution (bn_relu_conv3d sets it)
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, w, stride, padding, groups, relu, eps, momentum):
         lib = _lib.load()
+        pre = _BNReluConv3d._pre_stats
+        _BNReluConv3d._pre_stats = None
+        w_in, g_in, b_in = w, gamma, beta
         x = _req(x, "bn_relu_conv3d input")
         gamma, beta, w = _req(gamma, "bn weight"), _req(beta, "bn bias"), _req(w, "conv weight")
         n, c = x.shape[0], x.shape[1]
@@ -650,54 +660,110 @@ class _BNReluConv3d(torch.autograd.Function):
         mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
         ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device)
-        ws = _workspace(x.device, lib.cstp_bn_workspace_bytes(n, c, s, groups))
-        check(lib.cstp_bn_stats_train(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
-                                      _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), n, c, s, groups,
-                                      eps, momentum, ws.data_ptr(), ws.numel()), "cstp_bn_stats_train")
+        zam = None
+        with _span("bn_forward", (n, c, s, groups, False, bool(relu))):
+            if pre is not None:
+                zam = pre[2]       # zeroed by the producing launch; the finalize takes the maximum of act(x*scale+shift) into it
+                check(lib.cstp_bn_finalize_pre(_stream(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                               mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), n, c, s, groups, eps, momentum,
+                                               1 if relu else 0, pre[0].data_ptr(), pre[1], zam.data_ptr()), "cstp_bn_finalize_pre")
+            else:
+                ws = _workspace(x.device, lib.cstp_bn_workspace_bytes(n, c, s, groups))
+                check(lib.cstp_bn_stats_train(_stream(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(running_mean),
+                                              _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), ss.data_ptr(), n, c, s, groups,
+                                              eps, momentum, ws.data_ptr(), ws.numel()), "cstp_bn_stats_train")
         desc = _desc(x.shape, w.shape, stride, padding)
         y = torch.empty(conv_out_shape(x.shape, w.shape, stride, padding), dtype=torch.float32, device=x.device)
         ws = _workspace(x.device, lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)))
+        if AUTOTUNE:
+            _autotune(lib, desc, 0, x, w, y, ws)
         aff = InAffine(ss.data_ptr(), groups, 1 if relu else 0)
-        check(lib.cstp_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
-                                      y.data_ptr(), ws.data_ptr(), ws.numel()), "cstp_conv3d_forward")
+        with _span("conv3d_forward", lambda: _desc_key(desc)):
+            check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
+                                             y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(zam)), "cstp_conv3d_forward")
         ctx.save_for_backward(x, gamma, mean, invstd, ss, w)
-        ctx.desc, ctx.groups, ctx.relu = desc, groups, relu
+        ctx.desc, ctx.groups, ctx.relu, ctx.z_absmax = desc, groups, relu, zam
+        ctx.params = (g_in, b_in, w_in)      # the parameter objects themselves (their .grad may be an arena slice)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x, gamma, mean, invstd, ss, w = ctx.saved_tensors
-        desc = ctx.desc
+        desc, zam = ctx.desc, ctx.z_absmax
+        pg, pb, pw = ctx.params
+        dyam = _absmax_of(dy)
         dy = _req(dy, "bn_relu_conv3d grad_output")
         n, c = x.shape[0], x.shape[1]
         s = x.numel() // (n * c)
-        ws = _workspace(x.device, max(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)),
-                                      lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups)))
+        nbytes = max(lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), lib.cstp_bn_workspace_bytes(n, c, s, ctx.groups))
+        aff = InAffine(ss.data_ptr(), ctx.groups, 1 if ctx.relu else 0)
         dw = None
-        if ctx.needs_input_grad[5]:
+        direct_w = ctx.needs_input_grad[5] and _direct(pw)
+        side_w = direct_w and OVERLAP_WGRAD
+
+        def wgrad(dst, accumulate):
+            wsx = _workspace(x.device, nbytes)
+            if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 2) + _desc_key(desc) not in _tuned:
+                _autotune(lib, desc, 2, x, dy, torch.empty_like(w), wsx)          # (tuning overwrites its output)
+            with _span("conv3d_backward_weight", lambda: _desc_key(desc)):
+                check(lib.cstp_conv3d_backward_weight_acc(_stream(), ctypes.byref(desc), x.data_ptr(), ctypes.byref(aff),
+                                                          dy.data_ptr(), dst.data_ptr(), wsx.data_ptr(), wsx.numel(), _ptr(zam),
+                                                          _ptr(dyam), 1 if accumulate else 0), "cstp_conv3d_backward_weight")
+
+        if side_w:       # as _Conv3d.backward: the weight gradient feeds nothing downstream in the backward chain
+            main = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                wgrad(pw.grad, True)
+            for t in (x, dy, ss, zam, dyam):
+                if t is not None:
+                    t.record_stream(side)
+            _queue_join(x.device)
+        elif direct_w:
+            wgrad(pw.grad, True)
+        elif ctx.needs_input_grad[5]:
             dw = torch.empty_like(w)
-            aff = InAffine(ss.data_ptr(), ctx.groups, 1 if ctx.relu else 0)
-            check(lib.cstp_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), ctypes.byref(aff),
-                                                  dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel()),
-                  "cstp_conv3d_backward_weight")
+            wgrad(dw, False)
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            ws = _workspace(x.device, nbytes)
             dz = torch.empty_like(x)     # gradient w.r.t. the (never materialised) normalised activation
-            check(lib.cstp_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(),
-                                                ws.data_ptr(), ws.numel()), "cstp_conv3d_backward_data")
+            if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
+                _autotune(lib, desc, 1, dy, w, dz, ws)
+            with _span("conv3d_backward_data", lambda: _desc_key(desc)):
+                check(lib.cstp_conv3d_backward_data_acc(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), _ptr(dyam), 0), "cstp_conv3d_backward_data")
             dx = torch.empty_like(x)
-            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-            check(lib.cstp_bn_backward(_stream(), x.data_ptr(), None, dz.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                       invstd.data_ptr(), ss.data_ptr(), dx.data_ptr(), None, dgamma.data_ptr(),
-                                       dbeta.data_ptr(), n, c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel()),
-                  "cstp_bn_backward")
+            direct = ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _direct(pg) and _direct(pb)
+            dgamma = pg.grad if direct else torch.empty_like(gamma)
+            dbeta = pb.grad if direct else torch.empty_like(gamma)
+            cell = _new_cell(x)
+            with _span("bn_backward", (n, c, s, ctx.groups, False, bool(ctx.relu))):
+                check(lib.cstp_bn_backward_am(_stream(), x.data_ptr(), None, dz.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), ss.data_ptr(), dx.data_ptr(), None, dgamma.data_ptr(),
+                                              dbeta.data_ptr(), n, c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(),
+                                              ws.numel(), _ptr(cell), 1 if direct else 0), "cstp_bn_backward")
+            _tag_absmax(dx, cell)
+            if direct:
+                dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, dw, None, None, None, None, None, None
+
+
+def in_affine_fused(x_shape, w_shape, stride, padding, groups) -> bool:
+    """Would a convolution of this geometry apply a BatchNorm + ReLU over ``groups`` groups inside its f16-pair gather kernels
+    (forward AND weight gradient)?  cstp_conv3d_in_affine_fused."""
+    desc = _desc(tuple(x_shape), tuple(w_shape), _triple(stride), _triple(padding))
+    return bool(_lib.load().cstp_conv3d_in_affine_fused(ctypes.byref(desc), int(groups)))
 
 
 def bn_relu_conv3d(x, gamma, beta, running_mean, running_var, w, stride=1, padding=0, groups=1, relu=True, eps=BN_EPS,
                    momentum=BN_MOMENTUM):
-    """conv3d(act(batch_norm_train(x)), w) with the BN apply fused into the convolution's gather."""
+    """conv3d(act(batch_norm_train(x)), w) with the BN apply fused into the convolution's gather.  Where the convolution that
+    produced ``x`` left the BatchNorm's sums and range beside it (conv3d(.., bn_groups=groups)) no pass reads x before the
+    consuming convolution does."""
+    _BNReluConv3d._pre_stats = _bnstats_of(x, int(groups))
     return _BNReluConv3d.apply(x, gamma, beta, running_mean, running_var, w, _triple(stride), _triple(padding), int(groups),
                                bool(relu), float(eps), float(momentum))
 

@@ -30,6 +30,19 @@ from . import ops
 LAYER_SIZES = {1: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
 # Fold BN+ReLU into the consumer convolution's gather (ops.bn_relu_conv3d) instead of materialising it.
 FUSE_BN_INTO_CONV = os.environ.get("CSTP_FUSE_BN", "0") == "1"
+# Default path: the BatchNorm + ReLU between a stride-1 3x3 spatial convolution and its temporal convolution is applied inside
+# the temporal convolution's gather (forward and weight gradient, igemm_k1s / igemm_k2s <.., AFF>) wherever the spatial
+# convolution's kernel left the statistics AND the range of its output (igemm_k1p<MT, true>): the normalised mid-channel
+# tensor -- the largest activations of the network -- is never written or re-read.  CSTP_FUSE_BN_T=0 materialises it.
+FUSE_BN_TEMPORAL = os.environ.get("CSTP_FUSE_BN_T", "1") == "1"
+
+
+def _temporal_fused(x, conv, groups) -> bool:
+    # asked on every call (a plan lookup in the library): the answer follows the layer's CURRENT tiles, which the autotuner may
+    # still change during the first steps
+    return ops.in_affine_fused(x.shape, conv.weight.shape, conv.stride, conv.padding, groups)
+
+
 # Run the (no-grad) target-network forward on a second HIP stream, staggered behind the online network's stem + conv2 stage
 # (R21DBYOL.forward): -2.5 ms/step at cfg2 on MI355X.  CSTP_OVERLAP_TARGET=0 runs the two forwards back to back.
 OVERLAP_TARGET_FORWARD = os.environ.get("CSTP_OVERLAP_TARGET", "1") == "1"
@@ -208,9 +221,11 @@ class SpatioTemporalConv(nn.Module):
             return self.bn.relu_then(self.temporal_conv, x, groups)
         if pre_bn is not None:
             x = pre_bn(x, relu=True, groups=groups)
-        x = self.bn(self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean,
-                                      grad_join if pre_bn is None else None), relu=True, groups=groups)
-        return self.temporal_conv(x)
+        x = self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean, grad_join if pre_bn is None else None)
+        if (FUSE_BN_TEMPORAL and self.bn.training and ops._bnstats_of(x, groups) is not None
+                and _temporal_fused(x, self.temporal_conv, groups)):
+            return self.bn.relu_then(self.temporal_conv, x, groups)
+        return self.temporal_conv(self.bn(x, relu=True, groups=groups))
 
 
 class SpatioTemporalResBlock(nn.Module):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 15
+#define CSTP_ABI_VERSION 16
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -52,13 +52,19 @@ typedef struct cstp_in_affine {
   int32_t relu;   /* non-zero: z = max(z, 0) */
 } cstp_in_affine;
 
+/* 1 when BOTH the forward and the weight gradient of this geometry apply a cstp_in_affine over `groups` BatchNorm groups inside
+ * their f16-pair gather kernels (igemm_k1s / igemm_k2s <.., AFF>) given the transformed tensor's absmax cell; 0 = such a call
+ * would fall back to the native fp32 kernels (correct, much slower): callers then materialise the BatchNorm output instead. */
+int32_t cstp_conv3d_in_affine_fused(const cstp_conv_desc* desc, int32_t groups);
+
 int cstp_abi_version(void);
 const char* cstp_last_error(void);
 
 /* ---- convolution (F.conv3d / F.linear and their autograd) ------------------------------- */
 size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc);
 /* y[n][k][do][ho][wo] = conv3d(T(x), w) (+ bias[k] when bias != NULL).  w is [k][c][kt][kh][kw].
- * T = identity when in_affine == NULL, else the fused BN(+ReLU) input transform above. */
+ * T = identity when in_affine == NULL, else the fused BN(+ReLU) input transform above.  (The _am variants: with an in_affine the
+ * absmax cell is that of T(x), cstp_bn_finalize_pre.) */
 int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
                         const float* bias, const cstp_in_affine* in_affine, float* y, void* ws, size_t ws_bytes);
 /* dx = conv3d input gradient (aten::convolution_backward, input mask). */
@@ -84,14 +90,19 @@ int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float
  * per-channel, per-group sums of y and y^2 as fp64 partials part[k][groups][nsplit][2] (cstp_bn_forward_train_pre folds
  * them: the BatchNorm then needs no statistics pass over y).  *nsplit = partials per (channel, group), or 0 when this layer's
  * kernel cannot deliver them -- the call is then exactly cstp_conv3d_forward_am and BatchNorm takes its usual path.
- * cstp_conv3d_bnstats_nsplit: the same answer in advance (part needs k * groups * nsplit * 2 + k doubles).
+ * cstp_conv3d_bnstats_nsplit: the same answer in advance (part needs k * groups * nsplit * 3 + k doubles).
  * pivot (float[k] on the device, or NULL = zeros): the sums are taken AROUND it -- sum(y - pivot[ch]), sum((y - pivot[ch])^2) --
- * and the launch stores the values it used in the last k doubles of part; any finite values are correct, values near the
- * channel means (the BatchNorm's running_mean) keep the variance free of cancellation when |mean| >> std. */
+ * and the launch stores the values it used in the k doubles behind the sums; any finite values are correct, values near the
+ * channel means (the BatchNorm's running_mean) keep the variance free of cancellation when |mean| >> std.
+ * Behind the pivots the launch leaves every channel's smallest and largest output per group and partial
+ * (uint32 keys [k][groups][nsplit][2]): cstp_bn_finalize_pre turns them into the exact largest magnitude of the normalised
+ * tensor, so that the convolution consuming it can apply the BatchNorm in its own gather (cstp_in_affine) with the tensor
+ * never written.  z_cell (device uint32, or NULL): zeroed by this launch for that purpose (cstp_bn_finalize_pre takes the
+ * maximum into it with atomics). */
 int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups);
 int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y, void* ws,
                                 size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot, double* part,
-                                size_t part_bytes, int32_t* nsplit);
+                                size_t part_bytes, int32_t* nsplit, uint32_t* z_cell);
 int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
                                  void* ws, size_t ws_bytes, const uint32_t* dy_absmax);
 /* ... and with accumulate != 0: dx += the data gradient instead of dx = -- autograd's sum of the gradients of a tensor that
@@ -185,6 +196,15 @@ int cstp_bn_forward_train_pre(void* stream, const float* x, const float* residua
                               float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups,
                               float eps, float momentum, int32_t relu, void* ws, size_t ws_bytes, uint32_t* y_absmax,
                               const double* part, int32_t nsplit);
+/* The finalize step of cstp_bn_forward_train_pre ALONE (no pass over x, no output tensor): save_mean / save_invstd, the running
+ * statistics, the affine table scale_shift[groups][c][2] and -- from the minima / maxima cstp_conv3d_forward_bnstats left behind
+ * its sums -- the largest magnitude of act(x * scale + shift) over the whole tensor, bit-identical to what the apply pass of
+ * cstp_bn_forward_train_pre would have measured, taken into *z_cell with atomicMax (the cell must hold 0 or a lower bound: the
+ * producing launch zeroes the one it was given).  count = n * s / groups values per channel and group. */
+int cstp_bn_finalize_pre(void* stream, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float* save_mean, float* save_invstd, float* scale_shift, int32_t n, int32_t c, int32_t s,
+                         int32_t groups, float eps, float momentum, int32_t relu, const double* part, int32_t nsplit,
+                         uint32_t* z_cell);
 /* Statistics only: save_mean/save_invstd [groups][c], running stats update, and the affine table
  * scale_shift float[groups][c][2] = (invstd*gamma, beta - mean*invstd*gamma) that a consumer convolution
  * applies in its gather (cstp_in_affine) -- the BN output itself is never materialised. */
