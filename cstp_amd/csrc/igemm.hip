@@ -1258,7 +1258,7 @@ static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InA
 // straddle two BatchNorm groups.
 static bool aff_split_ok(const cstp_conv_desc& d, const InAffine& ia, const uint32_t* absmax, long out_positions_per_clip, int cols) {
   if (ia.ss == nullptr || absmax == nullptr || split_planes() != 2) return false;
-  if ((d.c & 15) != 0 || d.c > 1152 || ia.groups > 2) return false;      // (1152: the kernels' LDS tables)
+  if ((d.c & 15) != 0 || ia.groups > 2) return false;
   const long gpos = (long)ia.npg * out_positions_per_clip;
   return gpos % cols == 0 && gpos < (1l << 30);
 }

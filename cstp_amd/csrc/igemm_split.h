@@ -87,9 +87,9 @@ __device__ __forceinline__ void f16_scale(unsigned absmax_bits, float& scale, fl
 __device__ __forceinline__ void split2h(float x0, float x1, float sc, unsigned& h, unsigned& l) {
 #if CSTP_SPLIT_MIX
   unsigned hh, ll;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=&v"(hh) : "v"(x0), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(hh) : "v"(x0), "v"(sc));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(hh) : "v"(x1), "v"(sc));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(ll) : "v"(x0), "v"(sc), "v"(hh));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ll) : "v"(x0), "v"(sc), "v"(hh));
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll) : "v"(x1), "v"(sc), "v"(hh));
   h = hh;
   l = ll;
@@ -283,8 +283,9 @@ constexpr int STR_KMAX = 1056;                       // table entries: 7x7x7 tap
 // STAY 0 (zero padding applies to z): the clamp that implements the ReLU, med3(v, 0, cap), has cap = 0 at such positions.
 // Host conditions: Cs a multiple of 16, no column tile straddles two BatchNorm groups (aff_gpos positions per group, a
 // multiple of the tile's columns); *bcell is the largest magnitude of z (cstp_bn_finalize_pre).
+// (AFF, row tiles <= 4: THREE blocks per CU like the plain instantiation reaches by itself at 79 VGPRs)
 template <int MT, bool DGRAD, int NH, int NP, bool STR = false, bool AFF = false>
-__global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? 4 : 1)      // the f16-pair 128-column tiles: two blocks per CU (<= 128 VGPRs)
+__global__ void __launch_bounds__(512, (NP == 2 && NH == 1) ? ((AFF && MT <= 4) ? 6 : 4) : 1)      // the f16-pair 128-column tiles: two blocks per CU (<= 128 VGPRs)
 igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__ src, const float* __restrict__ bias,
           float* __restrict__ out, int n_tiles_x, int n_tiles_m, const float* __restrict__ inv_a,
           const unsigned* __restrict__ bcell, const float2* __restrict__ aff_ss, int aff_gpos, int aff_relu) {
@@ -304,8 +305,6 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     return NP == 2 ? ((plane * 4 + c) ^ (row & 7)) : (plane * 4 + (c ^ spl_swz(row)));
   };
   static_assert(!STR || (!DGRAD && NH == 1), "the straddle mode serves the forward 128-column tiles");
-  constexpr int AFF_MAXC = 1152;                    // AFF: channels of the gathered tensor (host-checked)
-  __shared__ __attribute__((aligned(16))) float aff_a[AFF ? AFF_MAXC : 4], aff_b[AFF ? AFF_MAXC : 4];   // scale / shift per channel
   __shared__ int vtap[28];                          // DGRAD: the taps that hit this stride-parity class, in order
   __shared__ __attribute__((aligned(16))) unsigned ktab[STR ? STR_KMAX : 4];   // STR: byte offset of reduction index k
   __shared__ __attribute__((aligned(16))) float inva_s[NP == 2 ? BM : 4];   // NP == 2: inverse row scales of this row tile
@@ -339,13 +338,6 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
 
   const int khw = g.kh * g.kw, ntaps = g.kt * khw;
   const int gpt = g.Cp >> 4;                         // 16-channel groups per tap
-
-  if constexpr (AFF) {
-    // my tile's BatchNorm group (uniform): its table goes to LDS once, the producers read it at every split
-    const float2* ssg = aff_ss + (size_t)(n0 / aff_gpos) * g.Cs;
-    for (int c = t; c < g.Cs; c += 512) { const float2 p = ssg[c]; aff_a[c] = p.x; aff_b[c] = p.y; }
-    __syncthreads();
-  }
 
   // ---- the tap sequence (block-uniform)
   int nvt = ntaps;
@@ -468,6 +460,7 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
     // AFF: what a register set needs at split time -- its channel block and, per position, the clamp's upper end
     struct AffSet { int cg; float cap[NH]; };
     AffSet as0 = {}, as1 = {};
+    const float2* const ssg = AFF ? aff_ss + (size_t)(n0 / aff_gpos) * g.Cs : nullptr;       // my tile's BatchNorm group (uniform)
 
     // issue the loads of my current group into the given register set, then advance to my next group
     auto issue_loads = [&](u32x4 (&ra)[A_IT], float (&rb)[NH][16], AffSet& as) __attribute__((always_inline)) {
@@ -516,26 +509,21 @@ igemm_k1s(const Geom g, const uint4* __restrict__ wps, const float* __restrict__
       for (int j = 0; j < A_IT; ++j)
         if (j < A_IT - 1 || a_last_ok) As[buf][a_lds[j]] = make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w);
       if constexpr (AFF) {
-        // the group's 16 scales and 16 shifts: same LDS address in every lane (broadcast reads), pairs of channels in adjacent
-        // registers -- one packed FMA per two elements, one clamp per element
+        // the group's 16 (scale, shift) pairs: wave-uniform, read with scalar loads (no vector registers: the kernel keeps its
+        // three blocks per CU); one packed FMA per two elements, one clamp per element
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x4* ta = reinterpret_cast<const f32x4*>(aff_a + (as.cg << 4));
-        const f32x4* tb = reinterpret_cast<const f32x4*>(aff_b + (as.cg << 4));
+        const float2* tb = ssg + (as.cg << 4);
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const f32x4 a4 = ta[j4], b4 = tb[j4];
+        for (int j = 0; j < 16; j += 2) {
+          const float2 p0 = tb[j], p1 = tb[j + 1];
+          const f32x2 a2 = {p0.x, p1.x}, b2 = {p0.y, p1.y};
 #pragma unroll
-          for (int jj = 0; jj < 4; jj += 2) {
-            const int j = 4 * j4 + jj;
-            const f32x2 a2 = {a4[jj], a4[jj + 1]}, b2 = {b4[jj], b4[jj + 1]};
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-              const f32x2 v2 = {rb[h][j], rb[h][j + 1]};
-              const f32x2 z2 = __builtin_elementwise_fma(v2, a2, b2);
-              const float lo = aff_relu ? 0.f : -as.cap[h];
-              rb[h][j] = __builtin_amdgcn_fmed3f(z2[0], lo, as.cap[h]);
-              rb[h][j + 1] = __builtin_amdgcn_fmed3f(z2[1], lo, as.cap[h]);
-            }
+          for (int h = 0; h < NH; ++h) {
+            const f32x2 v2 = {rb[h][j], rb[h][j + 1]};
+            const f32x2 z2 = __builtin_elementwise_fma(v2, a2, b2);
+            const float lo = aff_relu ? 0.f : -as.cap[h];
+            rb[h][j] = __builtin_amdgcn_fmed3f(z2[0], lo, as.cap[h]);
+            rb[h][j + 1] = __builtin_amdgcn_fmed3f(z2[1], lo, as.cap[h]);
           }
         }
       }
@@ -942,9 +930,18 @@ igemm_k2s(const Geom g, const float* __restrict__ dy, const float* __restrict__ 
         for (int j = 0; j < 2; ++j)
           rx[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, base_dy + mxoff[j], 0, 0));
       }
+      if constexpr (AFF) {
+        // whole 16-channel groups (host condition): no clamped channel -- one per-lane offset, the channel stride rides in the
+        // SCALAR offset (uniform), 15 registers and 15 additions per tile less
+        const unsigned vx = base_x + coff[0];
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, base_x + coff[j], 0, 0));
+        for (int j = 0; j < 16; ++j)
+          rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vx, (unsigned)j * ((unsigned)DHWs * 4u), 0));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, base_x + coff[j], 0, 0));
+      }
     };
 
     // img[p] = plane p of one operand image; sc = operand scale (NP == 2)
