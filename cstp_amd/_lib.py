@@ -64,7 +64,7 @@ SIGNATURES = {
                                             c_float, c_float, c_int32, _P, c_size_t, _P, _P, c_int32]),
     "cstp_conv3d_bnstats_nsplit": (c_int32, [POINTER(ConvDesc), c_int32]),
     "cstp_conv3d_forward_bnstats": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, c_int32, _P, _P, c_size_t,
-                                              POINTER(c_int32), _P]),
+                                              POINTER(c_int32), _P, _P]),
     "cstp_conv3d_in_affine_fused": (c_int32, [POINTER(ConvDesc), c_int32]),
     "cstp_bn_finalize_pre": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
                                        c_int32, _P, c_int32, _P]),

@@ -726,6 +726,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 }  // namespace cstp
 #include "igemm_split.h"
 #include "igemm_patch.h"
+#include "igemm_tpatch.h"
 #include "igemm_wpatch.h"
 namespace cstp {
 
@@ -756,6 +757,14 @@ static bool patch_geom_ok(const cstp_conv_desc& d) {
     return false;
   if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
   return patch_rows_needed(d.n * d.d, d.h, d.w) <= KP_ROWS;
+}
+// the temporal patch kernel igemm_k1t (igemm_tpatch.h): 3x1x1, stride 1, padding (1,0,0), f16 pair; tiles of 8 frames x 28
+// columns without remainder, whole 16-channel groups on both sides (the data gradient gathers the output channels)
+static bool tpatch_geom_ok(const cstp_conv_desc& d) {
+  if (!(d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 0 && d.pw == 0))
+    return false;
+  if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16 || (d.c & 15) != 0 || (d.k & 15) != 0) return false;
+  return d.d % KT_DT == 0 && (d.h * d.w) % KT_WT == 0;
 }
 // the weight-gradient patch kernel igemm_k2p (igemm_wpatch.h): the same layers; its x staging leads by <= 5 intervals of 64 rows
 static bool wpatch_geom_ok(const cstp_conv_desc& d) {
@@ -864,7 +873,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // the split kernels address their operands with 31-bit buffer offsets (bit 31 = "masked")
   const bool x_small = (size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 29);
   const bool y_small = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 29);
-  if (p.f_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.f_t.mt) && patch_geom_ok(d))) p.f_t = Tile{2, 1, 0, 1, 0};
+  if (p.f_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.f_t.mt) && (patch_geom_ok(d) || tpatch_geom_ok(d)))) p.f_t = Tile{2, 1, 0, 1, 0};
   // (the 3-channel stems run a split tile in its straddle mode: zero-padded input copy, per-k offset table, f16 pair only)
   const bool stem_split_ok = p.f_straddle && p.f_t.sp == 1 && p.f_t.wm == 1 && (p.f_t.mt >= 4 && p.f_t.mt <= 6) &&
                              split_planes() == 2 && p.ntaps * d.c <= STR_KMAX - 16 &&
@@ -879,7 +888,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   // dgrad: M = c, gather channels = k
   if (!lookup_tuned(d, 1, p.d_t))
     p.d_t = pick_tile(d.c, (long)d.n * cdiv(d.d, d.st) * cdiv(d.h, d.sh) * cdiv(d.w, d.sw), d.st * d.sh * d.sw);
-  if (p.d_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.d_t.mt) && patch_geom_ok(d))) p.d_t = Tile{2, 1, 0, 1, 0};
+  if (p.d_t.sp == 2 && !(x_small && y_small && patch_mt_ok(p.d_t.mt) && (patch_geom_ok(d) || tpatch_geom_ok(d)))) p.d_t = Tile{2, 1, 0, 1, 0};
   if (p.d_t.sp == 1 && (!y_small || p.ntaps > 27 || !split_tile_ok(p.d_t) || native_only())) p.d_t = Tile{2, 1, 0, 1, 0};
   p.d_Cp = (int)align_up(d.k, 16);
   p.d_Kp = p.ntaps * p.d_Cp;
@@ -1151,9 +1160,53 @@ static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups)
   return 8 * slots / nmblk;
 }
 
+// the temporal layers: igemm_k1t (same packed-weight format with three taps, same grid, same partial-sum table)
+static void run_k1t(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
+                    float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax, const K1pStats* st, bool accumulate,
+                    const InAffine* ia) {
+  TGeom g{};
+  g.Cs = dgrad ? d.k : d.c;
+  g.ncb = cdiv(g.Cs, 32);
+  g.D = d.d; g.HW = d.h * d.w; g.Nb = d.n;
+  g.M = dgrad ? d.c : d.k;
+  g.nwt = g.HW / KT_WT; g.ndt = d.d / KT_DT;
+  g.groups = st ? st->groups : 1;
+  g.gclips = st ? d.n / st->groups : 1;
+  g.acc = accumulate ? 1 : 0;
+  g.aff_npg = ia ? ia->npg : 1; g.aff_groups = ia ? ia->groups : 1; g.aff_relu = ia ? ia->relu : 0;
+  const int bm = 16 * tl.mt, nmblk = cdiv(g.M, bm);
+  const int ntiles = d.n * g.ndt * g.nwt;
+  unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
+  float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
+  hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nmblk * bm), dim3(256), 0, s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1,
+                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0, 3);
+  const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
+  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
+  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr);
+  dim3 grid((unsigned)(8 * slots), 1, 1);
+  double* part = st ? st->part : nullptr;
+  const float* pivot = st ? st->pivot : nullptr;
+  unsigned* zcell = st ? st->zcell : nullptr;
+  const float2* ss = ia ? ia->ss : nullptr;
+#define CSTP_K1T_(MT_, ST_, AF_) \
+  hipLaunchKernelGGL((igemm_k1t<MT_, ST_, AF_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot, zcell, ss)
+#define CSTP_K1T(MT_) \
+  do { \
+    if (part != nullptr && ss != nullptr) CSTP_K1T_(MT_, true, true); \
+    else if (part != nullptr) CSTP_K1T_(MT_, true, false); \
+    else if (ss != nullptr) CSTP_K1T_(MT_, false, true); \
+    else CSTP_K1T_(MT_, false, false); \
+  } while (0)
+  if (tl.mt == 4) CSTP_K1T(4); else if (tl.mt == 8) CSTP_K1T(8); else CSTP_K1T(9);
+#undef CSTP_K1T
+#undef CSTP_K1T_
+}
+
 static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* w, const float* src,
                     float* out, void* ws, size_t main_bytes, const uint32_t* src_absmax, const K1pStats* st = nullptr,
-                    bool accumulate = false) {
+                    bool accumulate = false, const InAffine* ia = nullptr) {
+  if (tpatch_geom_ok(d)) { run_k1t(tl, s, d, dgrad, w, src, out, ws, main_bytes, src_absmax, st, accumulate, ia); return; }
   PGeom g;
   g.acc = accumulate ? 1 : 0;
   g.gpos = st ? (int)((long)(d.n / st->groups) * d.d * d.h * d.w) : 1;
@@ -1169,7 +1222,7 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
   hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nmblk * bm), dim3(256), 0, s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1,
-                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0);
+                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0, 9);
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
@@ -1263,6 +1316,13 @@ static bool aff_split_ok(const cstp_conv_desc& d, const InAffine& ia, const uint
   return gpos % cols == 0 && gpos < (1l << 30);
 }
 
+// ... or the temporal patch kernel (igemm_k1t<.., AFF>): tables of both groups in LDS, the transform once per staged element
+static bool aff_tpatch_ok(const cstp_conv_desc& d, const Tile& t, const InAffine& ia, const uint32_t* absmax, const void* x, const void* y) {
+  if (ia.ss == nullptr || absmax == nullptr || t.sp != 2 || !tpatch_geom_ok(d)) return false;
+  if (ia.groups > 2 || d.c > KT_AFFC) return false;
+  return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
+
 }  // namespace cstp
 
 using namespace cstp;
@@ -1286,7 +1346,8 @@ extern "C" int32_t cstp_conv3d_in_affine_fused(const cstp_conv_desc* desc, int32
   InAffine ia{reinterpret_cast<const float2*>(desc), d.n / groups, groups, 1};       // (ss: any non-null pointer, never read here)
   const uint32_t* some = reinterpret_cast<const uint32_t*>(desc);
   const long S = (long)p.Do * p.Ho * p.Wo;
-  const bool fwd = p.f_t.sp == 1 && !p.f_straddle && aff_split_ok(d, ia, some, S, tile_bn(p.f_t));
+  const bool fwd = (p.f_t.sp == 1 && !p.f_straddle && aff_split_ok(d, ia, some, S, tile_bn(p.f_t))) ||
+                   aff_tpatch_ok(d, p.f_t, ia, some, nullptr, nullptr);
   const bool wgr = p.w_split && !p.w_straddle && !p.w_patch && aff_split_ok(d, ia, some, S, 32);
   return fwd && wgr ? 1 : 0;
 }
@@ -1299,21 +1360,26 @@ extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_
 
 extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y,
                                            void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot,
-                                           double* part, size_t part_bytes, int32_t* nsplit_out, uint32_t* z_cell) {
+                                           double* part, size_t part_bytes, int32_t* nsplit_out, uint32_t* z_cell,
+                                           const cstp_in_affine* in_affine) {
   CSTP_REQUIRE(desc && x && w && y && ws && part && nsplit_out, "null argument");
   ConvPlan p;
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  InAffine ia;
+  if (parse_in_affine(in_affine, *desc, ia)) return 1;
   const int ns = k1p_stats_nsplit(p.f_t, *desc, groups);
   *nsplit_out = 0;
-  if (ns == 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0)       // this layer's kernel cannot deliver the sums: plain forward
-    return cstp_conv3d_forward_am(stream, desc, x, w, nullptr, nullptr, y, ws, ws_bytes, x_absmax);
+  // this layer's kernel cannot deliver the sums (or cannot apply the input transform next to them): plain forward
+  if (ns == 0 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) != 0 ||
+      (ia.ss != nullptr && !aff_tpatch_ok(*desc, p.f_t, ia, x_absmax, x, y)))
+    return cstp_conv3d_forward_am(stream, desc, x, w, nullptr, in_affine, y, ws, ws_bytes, x_absmax);
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
   CSTP_REQUIRE(part_bytes >= ((size_t)desc->k * groups * ns * 3 + desc->k) * sizeof(double), "partial-sum buffer too small");
   const cstp_conv_desc& d = *desc;
   CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   const K1pStats st{part, groups, pivot, z_cell};
-  run_k1p(p.f_t, as_stream(stream), d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, &st);
+  run_k1p(p.f_t, as_stream(stream), d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, &st, false, ia.ss != nullptr ? &ia : nullptr);
   CSTP_LAUNCH_CHECK();
   *nsplit_out = ns;
   return 0;
@@ -1336,14 +1402,20 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
   // the fused input transform on the f16-pair gather kernel (igemm_k1s<.., AFF>): see aff_split_ok
   const bool aff_split = ia.ss != nullptr && p.f_t.sp == 1 && !p.f_straddle &&
                          aff_split_ok(d, ia, x_absmax, (long)p.Do * p.Ho * p.Wo, tile_bn(p.f_t));
-  if (p.f_t.sp != 0 && ia.ss != nullptr && !aff_split) {
+  const bool aff_tpatch = bias == nullptr && aff_tpatch_ok(d, p.f_t, ia, x_absmax, x, y);
+  // (the patch kernels store / load 16 bytes per lane: misaligned tensors take the gather kernel)
+  if (p.f_t.sp == 2 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0 && tpatch_geom_ok(d)) {
+    p.f_t = Tile{9, 1, 0, 1, 1};
+    p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
+  }
+  if (p.f_t.sp != 0 && ia.ss != nullptr && !aff_split && !aff_tpatch) {
     // no fused input transform on this layer's split kernel: such a call runs a native tile (and its operand padding)
     p.f_t = pick_tile(d.k, (long)d.n * p.Do * p.Ho * p.Wo, 1);
     if (p.f_t.sp) p.f_t = Tile{2, 1, 0, 1, 0};
     p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
   }
   if (p.f_t.sp == 2 && bias == nullptr) {
-    run_k1p(p.f_t, s, d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax);
+    run_k1p(p.f_t, s, d, false, w, x, y, ws, plan_main_bytes(d, p), x_absmax, nullptr, false, aff_tpatch ? &ia : nullptr);
     CSTP_LAUNCH_CHECK();
     return 0;
   }
@@ -1402,6 +1474,10 @@ extern "C" int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc*
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
+  if (p.d_t.sp == 2 && tpatch_geom_ok(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) != 0) {
+    p.d_t = Tile{9, 1, 0, 1, 1};
+    p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
+  }
   if (p.d_t.sp == 2) {
     run_k1p(p.d_t, s, d, true, w, dy, dx, ws, plan_main_bytes(d, p), dy_absmax, nullptr, accumulate != 0);
     CSTP_LAUNCH_CHECK();
@@ -1777,7 +1853,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     for (int mt = 4; mt <= 6; ++mt)
       if (cdiv(M, 16 * mt) * 16 * mt - M <= 16 + M / 8 && ncand < 40) cand[ncand++] = Tile{mt, 1, 0, 1, 1};
   }
-  if (allow_split && patch_geom_ok(d)) {       // the LDS-resident-patch kernel: row blocks of 64 / 128 / 144
+  if (allow_split && (patch_geom_ok(d) || tpatch_geom_ok(d))) {       // the LDS-resident-patch kernels: row blocks of 64 / 128 / 144
     static const int pmt[] = {4, 8, 9};
     int best_pad = 1 << 30;
     for (int mt : pmt) { const int pad = cdiv(M, 16 * mt) * 16 * mt - M; if (pad < best_pad) best_pad = pad; }

@@ -61,20 +61,21 @@ struct PGeom {
 // taps are mirrored: value(m = c_in, c = k_out, tap) = w[k_out][c_in][8 - tap].
 __global__ void __launch_bounds__(256)
 pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, float* __restrict__ inv_a,
-                          unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad) {
+                          unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad,
+                          int nt) {       // nt: filter taps (9: igemm_k1p; 3: the temporal layers' igemm_k1t)
   __shared__ unsigned red[4];
   const int m = blockIdx.x, t = threadIdx.x;
   if (m == 0 && t < ncells) cells[t] = 0;
   const int mreal = dgrad ? cin : kout, creal = dgrad ? kout : cin;
   auto fetch = [&](int c, int tap) __attribute__((always_inline)) -> float {
     if (m >= mreal || c >= creal) return 0.f;
-    return dgrad ? w[((size_t)c * cin + m) * 9 + (8 - tap)] : w[((size_t)m * cin + c) * 9 + tap];
+    return dgrad ? w[((size_t)c * cin + m) * nt + (nt - 1 - tap)] : w[((size_t)m * cin + c) * nt + tap];
   };
   // one item = 8 consecutive channels of one tap = one 16-byte chunk per plane
-  const int nitems = ncb * 9 * 4;
+  const int nitems = ncb * nt * 4;
   unsigned mx = 0;
   for (int it = t; it < nitems; it += 256) {
-    const int c8 = it & 3, kt = it >> 2, cb = kt / 9, tap = kt - cb * 9;
+    const int c8 = it & 3, kt = it >> 2, cb = kt / nt, tap = kt - cb * nt;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const unsigned a = __builtin_bit_cast(unsigned, fetch(cb * 32 + c8 * 8 + e, tap)) & 0x7fffffffu;
@@ -92,7 +93,7 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
   if (t == 0) inv_a[m] = inv;
   const int mblk = m / rows_per_blk, rloc = m - mblk * rows_per_blk;
   for (int it = t; it < nitems; it += 256) {
-    const int c8 = it & 3, kt = it >> 2, cb = kt / 9, tap = kt - cb * 9;
+    const int c8 = it & 3, kt = it >> 2, cb = kt / nt, tap = kt - cb * nt;
     uint4 ph, pl;
     unsigned hh, ll;
     const int c0 = cb * 32 + c8 * 8;
@@ -100,7 +101,7 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
     split2h(fetch(c0 + 2, tap), fetch(c0 + 3, tap), sc, hh, ll); ph.y = hh; pl.y = ll;
     split2h(fetch(c0 + 4, tap), fetch(c0 + 5, tap), sc, hh, ll); ph.z = hh; pl.z = ll;
     split2h(fetch(c0 + 6, tap), fetch(c0 + 7, tap), sc, hh, ll); ph.w = hh; pl.w = ll;
-    uint4* row = wpk + (((size_t)mblk * (ncb * 9) + kt) * rows_per_blk + rloc) * 8;
+    uint4* row = wpk + (((size_t)mblk * (ncb * nt) + kt) * rows_per_blk + rloc) * 8;
     row[c8 ^ (rloc & 7)] = ph;
     row[(4 + c8) ^ (rloc & 7)] = pl;
   }

@@ -1,0 +1,482 @@
+// K1T  igemm_k1t<MT>: forward / data gradient of the stride-1 3x1x1 TEMPORAL convolutions with the input patch resident in LDS --
+// igemm_k1p's scheme (igemm_patch.h: persistent blocks, packed weights by LDS-DMA into a ring of three K-tiles, consumers 2 x 2
+// with the transposed accumulator tile, BatchNorm sums / range from the epilogue) turned by ninety degrees: a block owns a tile of
+// 8 FRAMES x 28 COLUMNS = 224 output positions of one clip and keeps, per 32-channel block of the gathered tensor, those 28
+// columns of the 8 frames plus one halo frame before and after -- 10 x 28 = 280 LDS rows of split f16 pairs.  A temporal tap is
+// then a shift of 28 LDS rows: one gather + one split of 1.25 x the tile (1.0 x when the clip has 8 frames: the halo frames are
+// the zero padding) serve the three taps, where the gather kernel igemm_k1s fetches and splits every element once per tap.
+//
+// What the temporal layers change against igemm_k1p:
+//  * three K-tiles per channel block instead of nine, so the staging waves have a third of the time per staged element: they
+//    load FOUR consecutive columns of a channel per instruction (16 bytes per lane -- a frame row of the tile is 112 contiguous
+//    bytes) and a lane assembles the 8-channel chunks of its four LDS rows from eight such loads.  140 (row quad, 8-channel
+//    group) tasks per wave and channel block = three rounds of 64 lanes; round r of the channel block after next is loaded at
+//    K-tile r right after round r of the next one left its registers for LDS: 24 loads of 16 bytes in flight per lane.
+//  * AFF (forward): the gathered tensor is z = relu(src * scale + shift), the train-mode BatchNorm + ReLU between the spatial and
+//    the temporal convolution (r21d_byol.py:94-97), applied ONCE per element between load and split (igemm_k1s<.., AFF>
+//    pays it once per tap); the (scale, shift) tables of the (at most two) BatchNorm groups sit in LDS.  Halo frames are
+//    out-of-range loads (0) and stay 0 through the clamp med3(v, 0, cap) with cap = 0 there.
+//  * no ragged tiles (host: frames a multiple of 8, frame size a multiple of 28): every position of every tile is valid.
+#pragma once
+
+#include <type_traits>
+
+namespace cstp {
+
+constexpr int KT_DT = 8, KT_WT = 28;                 // tile: frames x columns (KT_DT * KT_WT == KP_NPOS)
+constexpr int KT_ROWS = (KT_DT + 2) * KT_WT;         // 280 LDS rows per patch buffer
+constexpr int KT_QUADS = KT_ROWS / 4;                // 70 quads of rows (four consecutive columns of one frame)
+constexpr int KT_TASKS = 2 * KT_QUADS;               // per staging wave and channel block: (quad, 8-channel group)
+constexpr int KT_NR = 3;                             // rounds of 64 tasks
+constexpr int KT_AFFC = 576;                         // AFF: channels the LDS tables hold (two groups)
+static_assert(KT_DT * KT_WT == KP_NPOS && KT_WT % 4 == 0 && KT_TASKS <= 64 * KT_NR, "tile shape");
+
+struct TGeom {
+  int Cs;           // channels of the gathered tensor (a multiple of 16)
+  int ncb;          // its 32-channel blocks
+  int D, HW, Nb;    // frames per clip, frame size, clips
+  int M;            // valid output rows (channels of `out`)
+  int nwt, ndt;     // tiles per frame row (HW / 28) and per clip depth (D / 8)
+  int gclips;       // STATS: clips per BatchNorm group of the OUTPUT
+  int groups;       // STATS: its groups (<= 2)
+  int acc;          // out += instead of out =
+  int aff_npg;      // AFF: clips per BatchNorm group of the INPUT transform
+  int aff_groups;   // AFF: its groups (<= 2)
+  int aff_relu;
+};
+
+template <int MT, bool STATS = false, bool AFF = false>
+__global__ void __launch_bounds__(512, 2)
+igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict__ src, float* __restrict__ out,
+          const float* __restrict__ inv_a, const unsigned* __restrict__ bcell, int ntiles, int nmblk, double* __restrict__ part,
+          const float* __restrict__ pivot, unsigned* __restrict__ zcell, const float2* __restrict__ aff_ss) {
+  constexpr int BM = 16 * MT;
+  constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
+  constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
+  constexpr int P_U4 = KT_ROWS * 8;
+  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
+  __shared__ __attribute__((aligned(16))) float aff_a[AFF ? 2 * KT_AFFC : 4], aff_b[AFF ? 2 * KT_AFFC : 4];
+  uint4* const ring = smem;
+  uint4* const patch = smem + 3 * A_U4;
+  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);      // [2][BM], by item parity
+  double* const stat_s = reinterpret_cast<double*>(smem + 3 * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // persistent blocks, work item = (position tile, row block), XCD-aware order: exactly igemm_k1p's
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int chunk = (ntiles + 7) >> 3;
+  int tiles_x = ntiles - xcd * chunk;
+  tiles_x = tiles_x < 0 ? 0 : (tiles_x < chunk ? tiles_x : chunk);
+  const int cnt_x = tiles_x * nmblk;
+  const int nitems = slot < cnt_x ? (cnt_x - slot + nslots - 1) / nslots : 0;
+  const int st_mblk = slot % nmblk, st_nsplit = (gridDim.x >> 3) * 8 / nmblk, st_j = xcd * (nslots / nmblk) + slot / nmblk;
+  auto write_part = [&](bool zeros) __attribute__((always_inline)) {
+    for (int e = threadIdx.x; e < g.groups * BM * 2; e += 256) {
+      const int k = e & 1, row = (e >> 1) % BM, grp = (e >> 1) / BM;
+      const int ch = st_mblk * BM + row;
+      if (ch < g.M) part[(((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2 + k] = zeros ? 0.0 : stat_s[(grp * BM + row) * 2 + k];
+    }
+    if (st_j == 0) {
+      for (int row = threadIdx.x; row < BM; row += 256) {
+        const int ch = st_mblk * BM + row;
+        if (ch < g.M) part[(size_t)g.M * g.groups * st_nsplit * 2 + ch] = pivot != nullptr ? (double)pivot[ch] : 0.0;
+      }
+    }
+  };
+  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
+  if constexpr (STATS) {
+    for (int e = threadIdx.x; e < g.groups * BM; e += 512) {
+      const int row = e % BM, grp = e / BM, ch = st_mblk * BM + row;
+      if (ch < g.M)
+        *reinterpret_cast<uint2*>(mmk + (((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2) = make_uint2(0xffffffffu, 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && zcell != nullptr) *zcell = 0;
+    __threadfence();
+  }
+  if (nitems == 0) {
+    if constexpr (STATS) { if (threadIdx.x < 256) write_part(true); }
+    return;
+  }
+  auto item_of = [&](int it, int& tile, int& mblk) __attribute__((always_inline)) {
+    const int idx = slot + it * nslots;
+    const int t_in = idx / nmblk;
+    mblk = idx - t_in * nmblk;
+    tile = xcd * chunk + t_in;
+  };
+  // tile -> (clip, first frame, first column); the column tiles of a frame row are neighbours in the order (shared cache lines)
+  auto tile_at = [&](int tile, int& nb, int& d0, int& hw0) __attribute__((always_inline)) {
+    const int wt = tile % g.nwt, rest = tile / g.nwt;
+    const int dt = rest % g.ndt;
+    nb = rest / g.ndt; d0 = dt * KT_DT; hw0 = wt * KT_WT;
+  };
+
+  const int HW = g.HW;
+  const int nkt = g.ncb * 3;
+  const size_t chs = (size_t)g.D * HW;               // channel stride of src / row stride of out (elements)
+
+  if constexpr (AFF) {
+    // the input transform's tables, both groups, once per block (read by the staging waves from their first store on: the
+    // barrier behind the prologue orders it)
+    for (int e = t; e < g.aff_groups * g.Cs; e += 512) {
+      const int grp = e / g.Cs, c = e - grp * g.Cs;
+      const float2 p = aff_ss[e];
+      aff_a[grp * KT_AFFC + c] = p.x; aff_b[grp * KT_AFFC + c] = p.y;
+    }
+    __syncthreads();
+  }
+
+  if (wave == 4 || wave == 5) {
+    // ============================================ weight DMA waves (4, 5): as igemm_k1p ============================================
+    constexpr int HALF_DMA = A_DMA / 2;
+    static_assert(A_DMA % 2 == 0, "two DMA waves share a K-tile's pieces evenly");
+    const int dw_ = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
+    int d_it = 0, d_kt = 0, d_mblk, tl_unused;
+    item_of(0, tl_unused, d_mblk);
+    int d_ring = 0;
+    auto dma_next = [&]() __attribute__((always_inline)) {
+      const unsigned so = (unsigned)((((size_t)d_mblk * nkt + d_kt) * A_U4) * 16);
+      uint4* dst = ring + d_ring * A_U4;
+#pragma unroll
+      for (int pc = 0; pc < HALF_DMA; ++pc) {
+        const int piece = dw_ * HALF_DMA + pc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
+                                                 (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
+      }
+      d_ring = d_ring == 2 ? 0 : d_ring + 1;          // (past the last item: the last K-tile again, into slots nobody reads)
+      if (d_it + 1 < nitems || d_kt + 1 < nkt) {
+        if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
+      }
+    };
+    dma_next();
+    dma_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int total = nitems * nkt;
+#pragma unroll 1
+    for (int k = 0; k < total; ++k) {
+      dma_next();                                     // K-tile k + 2 -> the slot K-tile k - 1 was read from
+      if constexpr (HALF_DMA == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if constexpr (HALF_DMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  if (wave >= 6) {
+    // ============================================ patch staging waves (6, 7) ============================================
+    // Wave 6 gathers channels 0..15 of each 32-channel block, wave 7 channels 16..31.  Task tk = lane + 64 r: row quad tk % 70
+    // (four consecutive columns of one patch frame), 8-channel group tk / 70.
+    const int half = wave - 6;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * chs * 4));
+    float sb, inv_unused;
+    f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sb, inv_unused);
+    const unsigned ch4 = (unsigned)(chs * 4);
+
+    int t_dl[KT_NR], t_j0[KT_NR], t_cg[KT_NR], t_row[KT_NR];
+    bool t_ok[KT_NR];
+#pragma unroll
+    for (int r = 0; r < KT_NR; ++r) {
+      const int tk = lane + 64 * r;
+      t_ok[r] = tk < KT_TASKS;
+      const int tq = t_ok[r] ? tk : 0;
+      t_cg[r] = tq / KT_QUADS;
+      const int quad = tq - t_cg[r] * KT_QUADS;
+      t_row[r] = 4 * quad;
+      t_dl[r] = t_row[r] / KT_WT;
+      t_j0[r] = t_row[r] - t_dl[r] * KT_WT;
+    }
+    // the load stream runs ahead of the consumers by two channel blocks: its own (item, channel block) cursor
+    int l_it = 0, l_cb = 0;
+    unsigned l_voff[KT_NR];
+    int l_grp = 0;
+    auto set_item = [&](int it) __attribute__((always_inline)) {
+      int tile, mb_unused, nb, d0, hw0;
+      if (it < nitems) {
+        item_of(it, tile, mb_unused);
+        tile_at(tile, nb, d0, hw0);
+        if (AFF) l_grp = nb / g.aff_npg;
+#pragma unroll
+        for (int r = 0; r < KT_NR; ++r) {
+          const int d = d0 - 1 + t_dl[r];
+          const bool ok = t_ok[r] && d >= 0 && d < g.D;
+          l_voff[r] = ok ? (unsigned)((((size_t)nb * g.Cs * g.D + d) * HW + hw0 + t_j0[r]) * 4) + (unsigned)(t_cg[r] * 8) * ch4 : OOB;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < KT_NR; ++r) l_voff[r] = OOB;
+      }
+    };
+    struct Round { u32x4 v[8]; int cb; int grp; float cap; };
+    auto load_round = [&](int r, Round& rd) __attribute__((always_inline)) {
+      // (channels past the tensor's last one: whole 16-channel halves, wave-uniform -- zeros against zero weights)
+      const bool have = l_cb * 32 + half * 16 < g.Cs;
+      const unsigned vo = have ? l_voff[r] : OOB;
+      const unsigned so = (unsigned)(l_cb * 32 + half * 16) * ch4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) buf_load_x4(rd.v[e], vo, rs_src, so + (unsigned)e * ch4);
+      rd.cb = l_cb; rd.grp = l_grp; rd.cap = vo != OOB ? __builtin_inff() : 0.f;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++l_cb == g.ncb) { l_cb = 0; ++l_it; set_item(l_it); }
+    };
+    auto store_round = [&](int buf, int r, Round& rd) __attribute__((always_inline)) {
+      float a[8], b[8];
+      if constexpr (AFF) {
+        int c0 = rd.cb * 32 + half * 16 + t_cg[r] * 8;
+        c0 = c0 < g.Cs ? c0 : 0;
+        const f32x4* ta = reinterpret_cast<const f32x4*>(aff_a + rd.grp * KT_AFFC + c0);
+        const f32x4* tb = reinterpret_cast<const f32x4*>(aff_b + rd.grp * KT_AFFC + c0);
+        const f32x4 a0 = ta[0], a1 = ta[1], b0 = tb[0], b1 = tb[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = a0[e]; a[4 + e] = a1[e]; b[e] = b0[e]; b[4 + e] = b1[e]; }
+      }
+      const float lo = g.aff_relu ? 0.f : -rd.cap;
+      f32x4 vf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vf[e] = __builtin_bit_cast(f32x4, rd.v[e]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                   // my four LDS rows
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          z[e] = vf[e][i];
+          if constexpr (AFF) z[e] = __builtin_amdgcn_fmed3f(__builtin_fmaf(z[e], a[e], b[e]), lo, rd.cap);
+        }
+        uint4 ph, pl;
+        unsigned hh, ll;
+        split2h(z[0], z[1], sb, hh, ll); ph.x = hh; pl.x = ll;
+        split2h(z[2], z[3], sb, hh, ll); ph.y = hh; pl.y = ll;
+        split2h(z[4], z[5], sb, hh, ll); ph.z = hh; pl.z = ll;
+        split2h(z[6], z[7], sb, hh, ll); ph.w = hh; pl.w = ll;
+        if (t_ok[r]) {
+          const int row = t_row[r] + i;
+          uint4* prow = patch + buf * P_U4 + row * 8;
+          const int c8 = 2 * half + t_cg[r], x7 = row & 7;
+          prow[c8 ^ x7] = ph;
+          prow[(4 + c8) ^ x7] = pl;
+        }
+      }
+    };
+
+    Round rd[KT_NR];
+    set_item(0);
+    // ---- prologue: channel block 0 of the first item into buffer 0, channel block 1's loads in flight
+#pragma unroll
+    for (int r = 0; r < KT_NR; ++r) load_round(r, rd[r]);
+#pragma unroll
+    for (int r = 0; r < KT_NR; ++r) store_round(0, r, rd[r]);
+    advance();
+#pragma unroll
+    for (int r = 0; r < KT_NR; ++r) load_round(r, rd[r]);
+    advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- steady state: during channel block X (three K-tiles) round r of block X + 1 goes to LDS and round r of block X + 2 is
+    // requested into the registers it left.  No load is conditional (past the end: out-of-range offsets).
+    const int total = nitems * g.ncb;
+    int pb = 0;
+#pragma unroll 1
+    for (int x = 0; x < total; ++x) {
+#pragma unroll
+      for (int r = 0; r < KT_NR; ++r) {
+        store_round(pb ^ 1, r, rd[r]);
+        load_round(r, rd[r]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      advance();
+      pb ^= 1;
+    }
+    return;
+  }
+
+  // =================================================== consumers (igemm_k1p's) ===================================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  constexpr int NIF = MT / 2;
+  const int mt0 = wm * NIF;
+  const int qa0 = fk ^ (fr & 7), qa1 = (4 + fk) ^ (fr & 7);
+  float invb, sc_unused;
+  f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sc_unused, invb);
+  const int q = lane >> 4;
+
+  if constexpr (STATS) {
+    for (int e = t; e < 2 * BM * 2; e += 256) stat_s[e] = 0.0;
+  }
+  __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
+  __builtin_amdgcn_s_setprio(2);
+
+  auto body = [&](auto xj0_tag, auto xjn_tag) __attribute__((always_inline)) {
+  constexpr int NI = NIF;
+  constexpr int XJ0 = decltype(xj0_tag)::value, XJN = decltype(xjn_tag)::value;      // the shared row tile: my column tiles of it
+  constexpr int XA = XJN > 0 ? 1 : 0;
+  int pb = 0;
+  for (int it = 0; it < nitems; ++it) {
+    int tile, mblk, nb, d0, hw0;
+    item_of(it, tile, mblk);
+    tile_at(tile, nb, d0, hw0);
+    float* const inva = inva_s + (it & 1) * BM;
+    if (t < BM) inva[t] = inv_a[mblk * BM + t];       // read back in this item's epilogue, many barriers later
+
+    f32x4 acc[NI][KP_NTW];
+    f32x4 accx[XJN > 0 ? XJN : 1];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < KP_NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (XJN > 0 ? XJN : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accx[j][r] = 0.f;
+
+    // LDS row of my position in each of my 7 column tiles at tap 0: the tile-local position itself (frame-major, 28 per
+    // frame, the patch starts one frame earlier); a tap adds 28
+    const int base0 = wn * (KP_NTW * 16) + fr;
+
+    f16x8 bh[3], bl[3];
+    const unsigned patch_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) uint4*)patch);
+    auto b_addr = [&](int j, unsigned pbuf_bytes, int ts) __attribute__((always_inline)) -> unsigned {
+      const int row = base0 + 16 * j + ts;
+      const int qq = fk ^ (row & 7);
+      return pbuf_bytes + (unsigned)(row * 8 + qq) * 16u;                      // the lo plane sits 4 chunks (64 bytes) away: ^ 64
+    };
+    auto issue_b = [&](f16x8& dh, f16x8& dl, unsigned addr) __attribute__((always_inline)) {
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(dh), "=&v"(dl) : "v"(addr), "v"(addr ^ 64u));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    issue_b(bh[0], bl[0], b_addr(0, patch_lds + pb * (P_U4 * 16), 0));
+    issue_b(bh[1], bl[1], b_addr(1, patch_lds + pb * (P_U4 * 16), 0));
+    const int arow0 = (mt0 * 16 + fr) * 8;
+    unsigned addr_n = b_addr(2, patch_lds + pb * (P_U4 * 16), 0);
+
+    int tap = 0, slot3 = 0;
+    auto ktile = [&](auto ph_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(ph_tag)::value;        // buffer of this K-tile's column tile 0
+      const uint4* Ab = ring + slot3 * A_U4;
+      const unsigned Bp = patch_lds + pb * (P_U4 * 16);
+      const int ts = tap * KT_WT;
+      int ntap = tap + 1, npb = pb;
+      if (ntap == 3) { ntap = 0; npb ^= 1; }
+      const unsigned Bn = patch_lds + npb * (P_U4 * 16);
+      const int nts = ntap * KT_WT;
+
+      f16x8 ah[NI + XA], al[NI + XA];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        ah[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa0]);
+        al[i] = __builtin_bit_cast(f16x8, Ab[arow0 + i * 128 + qa1]);
+      }
+      if constexpr (XA != 0) {                            // the shared last row tile
+        ah[NI] = __builtin_bit_cast(f16x8, Ab[((MT - 1) * 16 + fr) * 8 + qa0]);
+        al[NI] = __builtin_bit_cast(f16x8, Ab[((MT - 1) * 16 + fr) * 8 + qa1]);
+      }
+#pragma unroll
+      for (int j = 0; j < KP_NTW; ++j) {
+        issue_b(bh[(PH + j + 2) % 3], bl[(PH + j + 2) % 3], addr_n);
+        if (j + 3 < KP_NTW) addr_n = b_addr(j + 3, Bp, ts);
+        else addr_n = b_addr(j + 3 - KP_NTW, Bn, nts);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 bhj = bh[(PH + j) % 3], blj = bl[(PH + j) % 3];
+        const bool xj = XJN > 0 && j >= XJ0 && j < XJ0 + XJN;
+        const int jx = xj ? j - XJ0 : 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[NI + XA - 1], accx[jx], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blj, ah[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[i], acc[i][j], 0, 0, 0);
+        if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot3 = slot3 == 2 ? 0 : slot3 + 1;
+      tap = ntap; pb = npb;
+      __builtin_amdgcn_s_barrier();
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; kt += 3) {
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+      ktile(std::integral_constant<int, 2>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue (igemm_k1p's: transposed tile, one 16-byte store per lane and column tile).  A lane's four positions
+    // p0 .. p0 + 3 are columns j0 .. j0 + 3 of frame d0 + p0 / 28 (28 is a multiple of four: never across frames).
+    const int st_grp = STATS ? nb / g.gclips : 0;
+    size_t obase[KP_NTW];
+#pragma unroll
+    for (int j = 0; j < KP_NTW; ++j) {
+      const int p0 = (wn * KP_NTW + j) * 16 + 4 * q;
+      const int dl = p0 / KT_WT, jj = p0 - dl * KT_WT;
+      obase[j] = ((size_t)nb * g.M * g.D + d0 + dl) * HW + hw0 + jj;
+    }
+#pragma unroll
+    for (int i = 0; i < NI + XA; ++i) {
+      const int mrow = (i < NI ? (mt0 + i) : (MT - 1)) * 16 + fr;
+      const float sc = inva[mrow] * invb;
+      const int m = mblk * BM + mrow;
+      float* orow = out + (size_t)m * chs;
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+      float vmin = __builtin_inff(), vmax = -__builtin_inff();
+      float pv = 0.f;
+      if constexpr (STATS) { if (pivot != nullptr && m < g.M) pv = pivot[m] / sc; }
+#pragma unroll
+      for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
+        const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
+        if (m < g.M) {
+          f32x4* dst = reinterpret_cast<f32x4*>(orow + obase[j]);
+          *dst = g.acc ? *dst + v * sc : v * sc;
+        }
+        if constexpr (STATS) {
+          const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv;
+          vmin = __builtin_fminf(__builtin_fminf(vmin, v[0]), v[1]); vmin = __builtin_fminf(__builtin_fminf(vmin, v[2]), v[3]);
+          vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, v[0]), v[1]); vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, v[2]), v[3]);
+        }
+      }
+      if constexpr (STATS) {
+        float a = (s1[0] + s1[1]) + (s1[2] + s1[3]), b = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        if (q == 0 && m < g.M) {
+          double* dst = stat_s + (st_grp * BM + mrow) * 2;
+          __hip_atomic_fetch_add(dst, (double)(a * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(dst + 1, (double)(b * sc) * (double)sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 16, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 16, 64));
+        vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 32, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+        if (q == 0 && m < g.M) {
+          unsigned* mm = mmk + (((size_t)m * g.groups + st_grp) * st_nsplit + st_j) * 2;
+          atomicMin(mm, key_of_float(vmin * sc));
+          atomicMax(mm + 1, key_of_float(vmax * sc));
+        }
+      }
+    }
+  }
+  };
+  using std::integral_constant;
+  if constexpr (MT % 2 == 0) {
+    body(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+  } else {
+    if (wm == 0) body(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    else body(integral_constant<int, 4>{}, integral_constant<int, KP_NTW - 4>{});
+  }
+  if constexpr (STATS) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    write_part(false);
+  }
+}
+
+}  // namespace cstp

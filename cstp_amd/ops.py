@@ -395,7 +395,7 @@ class _Conv3d(torch.autograd.Function):
                     raise _lib.CstpError("BatchNorm pivot has %d entries for %d output channels" % (pv.numel(), w.shape[0]))
                 check(lib.cstp_conv3d_forward_bnstats(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), _ptr(xam), bn_groups, _ptr(pv), part.data_ptr(),
-                                                      part.numel() * 8, ctypes.byref(got), zcell.data_ptr()),
+                                                      part.numel() * 8, ctypes.byref(got), zcell.data_ptr(), None),
                       "cstp_conv3d_forward_bnstats")
                 if got.value > 0:
                     _Conv3d._last_stats = (part, got.value, bn_groups, zcell)
@@ -644,9 +644,11 @@ class _BNReluConv3d(torch.autograd.Function):
     recomputed in ITS gather (side stream, straight into the gradient arena), data gradient of the convolution, then the
     BN backward with the ReLU mask recomputed from x."""
     _pre_stats = None     # (partials, nsplit, cell) of the producing convolution (bn_relu_conv3d sets it)
+    _last_stats = None    # what THIS convolution left for the BatchNorm behind it (out_groups > 0), as _Conv3d._last_stats
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, w, stride, padding, groups, relu, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, w, stride, padding, groups, relu, eps, momentum,
+                out_groups=0, out_pivot=None):
         lib = _lib.load()
         pre = _BNReluConv3d._pre_stats
         _BNReluConv3d._pre_stats = None
@@ -678,9 +680,25 @@ class _BNReluConv3d(torch.autograd.Function):
         if AUTOTUNE:
             _autotune(lib, desc, 0, x, w, y, ws)
         aff = InAffine(ss.data_ptr(), groups, 1 if relu else 0)
+        # a train-mode BatchNorm over out_groups slices consumes y: where this layer's kernel can, it leaves that BatchNorm's
+        # sums and range beside y (the temporal patch kernel igemm_k1t<.., STATS, AFF>)
+        ns = lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), out_groups) if (out_groups > 0 and FUSE_BN_STATS) else 0
+        _BNReluConv3d._last_stats = None
         with _span("conv3d_forward", lambda: _desc_key(desc)):
-            check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
-                                             y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(zam)), "cstp_conv3d_forward")
+            if ns > 0:
+                part = torch.empty(w.shape[0] * out_groups * ns * 3 + w.shape[0], dtype=torch.float64, device=x.device)
+                ycell = torch.empty(1, dtype=torch.int32, device=x.device)
+                got = ctypes.c_int32(0)
+                pv = None if out_pivot is None else _req(out_pivot, "BatchNorm pivot")
+                check(lib.cstp_conv3d_forward_bnstats(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _ptr(zam), out_groups, _ptr(pv), part.data_ptr(),
+                                                      part.numel() * 8, ctypes.byref(got), ycell.data_ptr(), ctypes.byref(aff)),
+                      "cstp_conv3d_forward_bnstats")
+                if got.value > 0:
+                    _BNReluConv3d._last_stats = (part, got.value, out_groups, ycell)
+            else:
+                check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
+                                                 y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(zam)), "cstp_conv3d_forward")
         ctx.save_for_backward(x, gamma, mean, invstd, ss, w)
         ctx.desc, ctx.groups, ctx.relu, ctx.z_absmax = desc, groups, relu, zam
         ctx.params = (g_in, b_in, w_in)      # the parameter objects themselves (their .grad may be an arena slice)
@@ -748,7 +766,7 @@ class _BNReluConv3d(torch.autograd.Function):
             _tag_absmax(dx, cell)
             if direct:
                 dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, dw, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dw, None, None, None, None, None, None, None, None
 
 
 def in_affine_fused(x_shape, w_shape, stride, padding, groups) -> bool:
@@ -759,13 +777,18 @@ def in_affine_fused(x_shape, w_shape, stride, padding, groups) -> bool:
 
 
 def bn_relu_conv3d(x, gamma, beta, running_mean, running_var, w, stride=1, padding=0, groups=1, relu=True, eps=BN_EPS,
-                   momentum=BN_MOMENTUM):
+                   momentum=BN_MOMENTUM, bn_groups=0, bn_pivot=None):
     """conv3d(act(batch_norm_train(x)), w) with the BN apply fused into the convolution's gather.  Where the convolution that
     produced ``x`` left the BatchNorm's sums and range beside it (conv3d(.., bn_groups=groups)) no pass reads x before the
-    consuming convolution does."""
+    consuming convolution does.  ``bn_groups`` / ``bn_pivot``: as conv3d's -- the BatchNorm BEHIND this convolution."""
     _BNReluConv3d._pre_stats = _bnstats_of(x, int(groups))
-    return _BNReluConv3d.apply(x, gamma, beta, running_mean, running_var, w, _triple(stride), _triple(padding), int(groups),
-                               bool(relu), float(eps), float(momentum))
+    y = _BNReluConv3d.apply(x, gamma, beta, running_mean, running_var, w, _triple(stride), _triple(padding), int(groups),
+                            bool(relu), float(eps), float(momentum), int(bn_groups), bn_pivot)
+    st = _BNReluConv3d._last_stats
+    _BNReluConv3d._last_stats = None
+    if st is not None:
+        y._cstp_bnstats = st + (y._version,)
+    return y
 
 
 # ----------------------------------------------------------------------------------------------

@@ -133,13 +133,14 @@ class _BatchNorm(nn.Module):
             self.num_batches_tracked += groups   # else: one add per net per forward, see R21DBYOL.forward
         return y
 
-    def relu_then(self, conv, x, groups=1):
+    def relu_then(self, conv, x, groups=1, bn_groups=0, bn_pivot=None):
         """conv(relu(self(x))) with this BN's apply+ReLU folded into ``conv``'s gather: only the statistics
-        pass touches x before the convolution, and relu(bn(x)) is never written to HBM."""
+        pass touches x before the convolution, and relu(bn(x)) is never written to HBM.  ``bn_groups`` / ``bn_pivot``: the
+        BatchNorm behind ``conv`` (ops.conv3d)."""
         if not self.training:
             return conv(self(x, relu=True))
         y = ops.bn_relu_conv3d(x, self.weight, self.bias, self.running_mean, self.running_var, conv.weight, conv.stride,
-                               conv.padding, groups, True, self.eps, self.momentum)
+                               conv.padding, groups, True, self.eps, self.momentum, bn_groups, bn_pivot)
         if not getattr(self, "_nbt_in_arena", False):
             self.num_batches_tracked += groups
         return y
@@ -208,10 +209,12 @@ class SpatioTemporalConv(nn.Module):
         self.temporal_conv = Conv3d(intermed_channels, out_channels, (kernel_size[0], 1, 1), stride=(stride[0], 1, 1),
                                     padding=(padding[0], 0, 0), bias=bias)
 
-    def forward(self, x, groups=1, pre_bn=None, grad_join=None):
+    def forward(self, x, groups=1, pre_bn=None, grad_join=None, out_bn=None):
         """temporal_conv(relu(bn(spatial_conv(x)))) (r21d_byol.py:94-97).  ``grad_join``: x feeds a second op of the block
         as well (the residual / the shortcut): their gradients are summed inside the ops (ops.GradJoin).  ``pre_bn``: the BatchNorm whose
-        apply+ReLU precedes this module in the block (bn1 -> relu1 -> conv2, :142-143).
+        apply+ReLU precedes this module in the block (bn1 -> relu1 -> conv2, :142-143).  ``out_bn``: the BatchNorm that consumes this
+        module's output (bn1 / bn2 / downsamplebn, :142-147): in train mode the temporal convolution leaves its statistics where
+        its kernel can.
         With FUSE_BN_INTO_CONV each BN+ReLU is folded into the following convolution's gather (the normalised
         tensor is never written: -36 % BN traffic, -7 ms/step of BN kernels, -7 GB of activations at cfg2) --
         but the per-element affine costs the MFMA kernels' gather more than the two HBM passes it removes
@@ -222,10 +225,12 @@ class SpatioTemporalConv(nn.Module):
         if pre_bn is not None:
             x = pre_bn(x, relu=True, groups=groups)
         x = self.spatial_conv(x, groups if self.bn.training else 0, self.bn.running_mean, grad_join if pre_bn is None else None)
+        og = groups if (out_bn is not None and out_bn.training) else 0
+        opv = out_bn.running_mean if og else None
         if (FUSE_BN_TEMPORAL and self.bn.training and ops._bnstats_of(x, groups) is not None
                 and _temporal_fused(x, self.temporal_conv, groups)):
-            return self.bn.relu_then(self.temporal_conv, x, groups)
-        return self.temporal_conv(self.bn(x, relu=True, groups=groups))
+            return self.bn.relu_then(self.temporal_conv, x, groups, og, opv)
+        return self.temporal_conv(self.bn(x, relu=True, groups=groups), og, opv)
 
 
 class SpatioTemporalResBlock(nn.Module):
@@ -249,9 +254,10 @@ class SpatioTemporalResBlock(nn.Module):
         # the block's input feeds two ops -- conv1 and the residual addition (or, in a downsample block, conv1 and the shortcut
         # convolution): their two gradients are summed inside the second op's kernel instead of by a separate add pass
         join = ops.GradJoin(2) if (self.training and torch.is_grad_enabled() and x.requires_grad and not FUSE_BN_INTO_CONV) else None
-        res = self.conv2(self.conv1(x, groups, grad_join=join), groups, pre_bn=self.bn1)   # conv2(relu1(bn1(conv1(x))))
+        # conv2(relu1(bn1(conv1(x))))
+        res = self.conv2(self.conv1(x, groups, grad_join=join, out_bn=self.bn1), groups, pre_bn=self.bn1, out_bn=self.bn2)
         if self.downsample:
-            x = self.downsamplebn(self.downsampleconv(x, groups, grad_join=join), groups=groups)
+            x = self.downsamplebn(self.downsampleconv(x, groups, grad_join=join, out_bn=self.downsamplebn), groups=groups)
             join = None
         # relu(x + bn2(res)) as one kernel (r21d_byol.py:143,148)
         return self.bn2(res, residual=x, relu=True, groups=groups, grad_join=join)

@@ -98,11 +98,12 @@ int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float
  * (uint32 keys [k][groups][nsplit][2]): cstp_bn_finalize_pre turns them into the exact largest magnitude of the normalised
  * tensor, so that the convolution consuming it can apply the BatchNorm in its own gather (cstp_in_affine) with the tensor
  * never written.  z_cell (device uint32, or NULL): zeroed by this launch for that purpose (cstp_bn_finalize_pre takes the
- * maximum into it with atomics). */
+ * maximum into it with atomics).  in_affine (or NULL): the input transform of cstp_conv3d_forward_am, for a temporal
+ * convolution that consumes one BatchNorm inside its gather and feeds the next (x_absmax is then that of T(x)). */
 int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups);
 int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y, void* ws,
                                 size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot, double* part,
-                                size_t part_bytes, int32_t* nsplit, uint32_t* z_cell);
+                                size_t part_bytes, int32_t* nsplit, uint32_t* z_cell, const cstp_in_affine* in_affine);
 int cstp_conv3d_backward_data_am(void* stream, const cstp_conv_desc* desc, const float* dy, const float* w, float* dx,
                                  void* ws, size_t ws_bytes, const uint32_t* dy_absmax);
 /* ... and with accumulate != 0: dx += the data gradient instead of dx = -- autograd's sum of the gradients of a tensor that

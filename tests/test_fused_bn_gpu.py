@@ -20,6 +20,9 @@ FUSED_GEOMS = {
     "two row blocks, 256-column tile": ((4, 32, 8, 28, 28), 288, 128, 9, (1, 8, 2, 0), (1, 8, 8, 0)),
     "144-row temporal tile": ((4, 16, 4, 28, 28), 48, 144, 9, (1, 9, 0, 0), (1, 9, 8, 0)),
     "64-row spatial tiles": ((2, 32, 2, 56, 56), 64, 48, 4, (1, 3, 0, 0), (1, 4, 4, 0)),
+    # the temporal convolution on the LDS-resident-patch kernel igemm_k1t: the transform once per staged element
+    "temporal patch kernel, 64 rows": ((4, 16, 8, 28, 28), 144, 64, 9, (2, 4, 0, 0), (1, 4, 8, 0)),
+    "temporal patch kernel, 144 rows": ((2, 16, 16, 28, 28), 48, 144, 9, (2, 9, 0, 0), (1, 9, 8, 0)),
 }
 
 
