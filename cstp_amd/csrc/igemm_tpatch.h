@@ -127,24 +127,21 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     __syncthreads();
   }
 
-  if (wave == 4 || wave == 5) {
-    // ============================================ weight DMA waves (4, 5): as igemm_k1p ============================================
-    constexpr int HALF_DMA = A_DMA / 2;
-    static_assert(A_DMA % 2 == 0, "two DMA waves share a K-tile's pieces evenly");
-    const int dw_ = wave - 4;
+  if (wave == 4) {
+    // ============================================ weight DMA wave (4) ============================================
+    // All 1 KiB pieces of K-tile k + 2 are requested at K-tile k; this wave issues no other vector-memory instruction, so its
+    // wait is COUNTED (the batch just issued stays in flight across the barrier).  (The patch loads below stay in flight for
+    // six K-tiles: in a wave that also waited for weight pieces, the in-order counter would retire them K-tile by K-tile.)
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
-    int d_it = 0, d_kt = 0, d_mblk, tl_unused;
+    int d_it = 0, d_kt = 0, d_mblk, tl_unused, d_ring = 0;
     item_of(0, tl_unused, d_mblk);
-    int d_ring = 0;
     auto dma_next = [&]() __attribute__((always_inline)) {
       const unsigned so = (unsigned)((((size_t)d_mblk * nkt + d_kt) * A_U4) * 16);
       uint4* dst = ring + d_ring * A_U4;
 #pragma unroll
-      for (int pc = 0; pc < HALF_DMA; ++pc) {
-        const int piece = dw_ * HALF_DMA + pc;
+      for (int piece = 0; piece < A_DMA; ++piece)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
                                                  (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
-      }
       d_ring = d_ring == 2 ? 0 : d_ring + 1;          // (past the last item: the last K-tile again, into slots nobody reads)
       if (d_it + 1 < nitems || d_kt + 1 < nkt) {
         if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
@@ -155,68 +152,70 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int total = nitems * nkt;
+    static_assert(A_DMA == 8 || A_DMA == 16 || A_DMA == 18, "the counted wait below lists the piece counts");
 #pragma unroll 1
     for (int k = 0; k < total; ++k) {
       dma_next();                                     // K-tile k + 2 -> the slot K-tile k - 1 was read from
-      if constexpr (HALF_DMA == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else if constexpr (HALF_DMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (A_DMA == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if constexpr (A_DMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     return;
   }
 
-  if (wave >= 6) {
-    // ============================================ patch staging waves (6, 7) ============================================
-    // Wave 6 gathers channels 0..15 of each 32-channel block, wave 7 channels 16..31.  Task tk = lane + 64 r: row quad tk % 70
-    // (four consecutive columns of one patch frame), 8-channel group tk / 70.
-    const int half = wave - 6;
+  if (wave >= 5) {
+    // ============================================ patch staging waves (5, 6, 7) ============================================
+    // Staging task tk = (row quad tk % 70, 8-channel group tk / 70 of the 32-channel block): 280 tasks per channel block, 94
+    // (93 for the last) per wave = a full round of 64 lanes and a round of 30.  The registers of a round hold channel block
+    // X + 2 or X + 3 while block X is multiplied: at the first K-tile of X the first round of block X + 1 goes to LDS and the
+    // loads of block X + 3 are issued into the registers it left, at the second K-tile the same for the second round -- 16
+    // loads of 16 bytes in flight per lane, two channel blocks (six K-tiles) of latency.
+    const int sw = wave - 5;
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * chs * 4));
     float sb, inv_unused;
     f16_scale(__builtin_amdgcn_readfirstlane(*bcell), sb, inv_unused);
     const unsigned ch4 = (unsigned)(chs * 4);
+    constexpr int TPW = (4 * KT_QUADS + 2) / 3;        // 94 tasks per wave
 
-    int t_dl[KT_NR], t_j0[KT_NR], t_cg[KT_NR], t_row[KT_NR];
-    bool t_ok[KT_NR];
-#pragma unroll
-    for (int r = 0; r < KT_NR; ++r) {
-      const int tk = lane + 64 * r;
-      t_ok[r] = tk < KT_TASKS;
-      const int tq = t_ok[r] ? tk : 0;
-      t_cg[r] = tq / KT_QUADS;
-      const int quad = tq - t_cg[r] * KT_QUADS;
-      t_row[r] = 4 * quad;
-      t_dl[r] = t_row[r] / KT_WT;
-      t_j0[r] = t_row[r] - t_dl[r] * KT_WT;
-    }
-    // the load stream runs ahead of the consumers by two channel blocks: its own (item, channel block) cursor
-    int l_it = 0, l_cb = 0;
-    unsigned l_voff[KT_NR];
-    int l_grp = 0;
+    struct Task { int row, dl, j0, c8; bool ok; };
+    auto task_of = [&](int tk, bool ok) __attribute__((always_inline)) -> Task {
+      Task k;
+      k.ok = ok && tk < 4 * KT_QUADS;
+      const int tq = k.ok ? tk : 0;
+      k.c8 = tq / KT_QUADS;
+      const int quad = tq - k.c8 * KT_QUADS;
+      k.row = 4 * quad;
+      k.dl = k.row / KT_WT;
+      k.j0 = k.row - k.dl * KT_WT;
+      return k;
+    };
+    const Task tm = task_of(TPW * sw + lane, true);
+    const Task tt = task_of(TPW * sw + 64 + lane, lane < TPW - 64);
+    // the load stream runs ahead of the consumers by up to three channel blocks: its own (item, channel block) cursor
+    int l_it = 0, l_cb = 0, l_grp = 0;
+    unsigned l_vm = OOB, l_vt = OOB;
     auto set_item = [&](int it) __attribute__((always_inline)) {
-      int tile, mb_unused, nb, d0, hw0;
+      l_vm = OOB; l_vt = OOB;
       if (it < nitems) {
+        int tile, mb_unused, nb, d0, hw0;
         item_of(it, tile, mb_unused);
         tile_at(tile, nb, d0, hw0);
         if (AFF) l_grp = nb / g.aff_npg;
-#pragma unroll
-        for (int r = 0; r < KT_NR; ++r) {
-          const int d = d0 - 1 + t_dl[r];
-          const bool ok = t_ok[r] && d >= 0 && d < g.D;
-          l_voff[r] = ok ? (unsigned)((((size_t)nb * g.Cs * g.D + d) * HW + hw0 + t_j0[r]) * 4) + (unsigned)(t_cg[r] * 8) * ch4 : OOB;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < KT_NR; ++r) l_voff[r] = OOB;
+        const int dm = d0 - 1 + tm.dl, dt = d0 - 1 + tt.dl;
+        if (tm.ok && dm >= 0 && dm < g.D)
+          l_vm = (unsigned)((((size_t)nb * g.Cs * g.D + dm) * HW + hw0 + tm.j0) * 4) + (unsigned)(tm.c8 * 8) * ch4;
+        if (tt.ok && dt >= 0 && dt < g.D)
+          l_vt = (unsigned)((((size_t)nb * g.Cs * g.D + dt) * HW + hw0 + tt.j0) * 4) + (unsigned)(tt.c8 * 8) * ch4;
       }
     };
     struct Round { u32x4 v[8]; int cb; int grp; float cap; };
-    auto load_round = [&](int r, Round& rd) __attribute__((always_inline)) {
-      // (channels past the tensor's last one: whole 16-channel halves, wave-uniform -- zeros against zero weights)
-      const bool have = l_cb * 32 + half * 16 < g.Cs;
-      const unsigned vo = have ? l_voff[r] : OOB;
-      const unsigned so = (unsigned)(l_cb * 32 + half * 16) * ch4;
+    auto load_round = [&](const Task& k, unsigned voff, Round& rd) __attribute__((always_inline)) {
+      // (channels past the tensor's last one: whole 16-channel groups -- zeros against zero weights)
+      const bool have = l_cb * 32 + k.c8 * 8 < g.Cs;
+      const unsigned vo = have ? voff : OOB;
+      const unsigned so = (unsigned)(l_cb * 32) * ch4;
 #pragma unroll
       for (int e = 0; e < 8; ++e) buf_load_x4(rd.v[e], vo, rs_src, so + (unsigned)e * ch4);
       rd.cb = l_cb; rd.grp = l_grp; rd.cap = vo != OOB ? __builtin_inff() : 0.f;
@@ -224,10 +223,10 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     auto advance = [&]() __attribute__((always_inline)) {
       if (++l_cb == g.ncb) { l_cb = 0; ++l_it; set_item(l_it); }
     };
-    auto store_round = [&](int buf, int r, Round& rd) __attribute__((always_inline)) {
+    auto store_round = [&](int buf, const Task& k, Round& rd) __attribute__((always_inline)) {
       float a[8], b[8];
       if constexpr (AFF) {
-        int c0 = rd.cb * 32 + half * 16 + t_cg[r] * 8;
+        int c0 = rd.cb * 32 + k.c8 * 8;
         c0 = c0 < g.Cs ? c0 : 0;
         const f32x4* ta = reinterpret_cast<const f32x4*>(aff_a + rd.grp * KT_AFFC + c0);
         const f32x4* tb = reinterpret_cast<const f32x4*>(aff_b + rd.grp * KT_AFFC + c0);
@@ -236,6 +235,7 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         for (int e = 0; e < 4; ++e) { a[e] = a0[e]; a[4 + e] = a1[e]; b[e] = b0[e]; b[4 + e] = b1[e]; }
       }
       const float lo = g.aff_relu ? 0.f : -rd.cap;
+      // (the components through a float vector: indexing rd.v[e][i] directly made hipcc read component 0 for every i)
       f32x4 vf[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vf[e] = __builtin_bit_cast(f32x4, rd.v[e]);
@@ -253,44 +253,55 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         split2h(z[2], z[3], sb, hh, ll); ph.y = hh; pl.y = ll;
         split2h(z[4], z[5], sb, hh, ll); ph.z = hh; pl.z = ll;
         split2h(z[6], z[7], sb, hh, ll); ph.w = hh; pl.w = ll;
-        if (t_ok[r]) {
-          const int row = t_row[r] + i;
+        if (k.ok) {
+          const int row = k.row + i;
           uint4* prow = patch + buf * P_U4 + row * 8;
-          const int c8 = 2 * half + t_cg[r], x7 = row & 7;
-          prow[c8 ^ x7] = ph;
-          prow[(4 + c8) ^ x7] = pl;
+          const int x7 = row & 7;
+          prow[k.c8 ^ x7] = ph;
+          prow[(4 + k.c8) ^ x7] = pl;
         }
       }
     };
 
-    Round rd[KT_NR];
+    Round rm[2], rt[2];                                // by parity of the channel block they carry
     set_item(0);
-    // ---- prologue: channel block 0 of the first item into buffer 0, channel block 1's loads in flight
-#pragma unroll
-    for (int r = 0; r < KT_NR; ++r) load_round(r, rd[r]);
-#pragma unroll
-    for (int r = 0; r < KT_NR; ++r) store_round(0, r, rd[r]);
+    // ---- prologue: channel block 0 of the first item into buffer 0; blocks 1 and 2 requested
+    load_round(tm, l_vm, rm[0]);
+    load_round(tt, l_vt, rt[0]);
+    store_round(0, tm, rm[0]);
+    store_round(0, tt, rt[0]);
     advance();
-#pragma unroll
-    for (int r = 0; r < KT_NR; ++r) load_round(r, rd[r]);
+    load_round(tm, l_vm, rm[1]);
+    load_round(tt, l_vt, rt[1]);
+    advance();
+    load_round(tm, l_vm, rm[0]);
+    load_round(tt, l_vt, rt[0]);
     advance();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- steady state: during channel block X (three K-tiles) round r of block X + 1 goes to LDS and round r of block X + 2 is
-    // requested into the registers it left.  No load is conditional (past the end: out-of-range offsets).
+    // ---- steady state.  No load is conditional (past the end: out-of-range offsets).
     const int total = nitems * g.ncb;
+    auto cblock = [&](auto par_tag, int pbuf) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_tag)::value;    // parity of block X + 1 = the register set that goes to LDS
+      store_round(pbuf ^ 1, tm, rm[PAR]);               // K-tile 0: first round
+      load_round(tm, l_vm, rm[PAR]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      store_round(pbuf ^ 1, tt, rt[PAR]);               // K-tile 1: second round
+      load_round(tt, l_vt, rt[PAR]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                     // K-tile 2
+      advance();
+    };
     int pb = 0;
 #pragma unroll 1
-    for (int x = 0; x < total; ++x) {
-#pragma unroll
-      for (int r = 0; r < KT_NR; ++r) {
-        store_round(pb ^ 1, r, rd[r]);
-        load_round(r, rd[r]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      advance();
+    for (int x = 0; x < total; x += 2) {
+      cblock(std::integral_constant<int, 1>{}, pb);      // block x: block x + 1 (odd) goes to LDS
+      pb ^= 1;
+      if (x + 1 >= total) break;
+      cblock(std::integral_constant<int, 0>{}, pb);
       pb ^= 1;
     }
     return;
