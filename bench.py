@@ -293,6 +293,18 @@ def main():
                     lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(ops.ConvDesc(*d_s1)), 2) > 0
                 per_elem = (8.0 if pre else 12.0) if what == "bn_forward" else 20.0      # bwd: (x, dy) twice + dx
                 nbytes = per_elem * n * c * s
+                # ... and since round 3 its apply + ReLU runs inside the temporal convolution's gather (the T1 fwd row carries it):
+                # what is left under this span is cstp_bn_finalize_pre, one wave per channel over the partial sums
+                from cstp_amd import r21d_byol as _rb
+                if what == "bn_forward" and pre and _rb.FUSE_BN_TEMPORAL and \
+                        ops.in_affine_fused(d_t1[:5], (d_t1[5], d_t1[1]) + tuple(d_t1[6:9]), d_t1[9:12], d_t1[12:15], 2):
+                    row.update({"bound": "latency", "algorithmic_bytes": 0.0,
+                                "bytes_note": "statistics folded from the producing convolution's partial sums (cstp_bn_finalize_pre); "
+                                              "the apply + ReLU is part of the T1 fwd row (in_affine): the normalised tensor is never written"})
+                    row["hbm_tbs"] = 0.0
+                    row["frac_hbm"] = 0.0
+                    kernels.append(row)
+                    continue
                 row.update({"bound": "hbm", "algorithmic_bytes": nbytes,
                             "bytes_note": "%d B/element: %s" % (per_elem, ("statistics from the producing convolution's epilogue; "
                                           "apply pass reads x and writes y" if pre else "statistics pass reads x, apply pass reads "
