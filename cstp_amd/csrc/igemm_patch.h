@@ -26,6 +26,9 @@
 
 #include <type_traits>
 
+#ifndef KP_RING6
+#define KP_RING6 0    // 1: six-slot weight ring at 64 rows (measured neutral: 58.19 vs 58.11 ms/step -- the weight DMA is not what the short K-tiles wait for)
+#endif
 #ifndef KP_DIAG
 #define KP_DIAG 0     // timing-only diagnostic builds (wrong results): bit 0 = no patch staging after the prologue, bit 1 = no weight
 #endif                // DMA after the prologue, bit 2 = no products, bit 3 = no output stores
@@ -137,11 +140,15 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
   constexpr int P_U4 = KP_ROWS * 8;
-  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
+  // Weight ring: three K-tiles where LDS is full (128 / 144 rows); SIX at 64 rows -- a K-tile of 42 products per consumer wave
+  // lasts ~0.3 us, and a weight piece requested two K-tiles ahead (0.6 us) is not back from L2 when its K-tile starts: the
+  // DMA waves' wait, and behind it the barrier, set the K-tile time.  Five K-tiles of lead cost 24 KB.
+  constexpr int RING = KP_RING6 && MT == 4 ? 6 : 3;
+  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
   uint4* const ring = smem;
-  uint4* const patch = smem + 3 * A_U4;
-  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);      // [2][BM], by item parity
-  double* const stat_s = reinterpret_cast<double*>(smem + 3 * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
+  uint4* const patch = smem + RING * A_U4;
+  float* const inva_s = reinterpret_cast<float*>(smem + RING * A_U4 + 2 * P_U4);      // [2][BM], by item parity
+  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -210,13 +217,14 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     static_assert(A_DMA % 2 == 0, "two DMA waves share a K-tile's pieces evenly");
     const int dw_ = wave - 4;
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wpk, (unsigned)((size_t)nmblk * nkt * A_U4 * 16));
-    int d_it = 0, d_kt = 0, d_mblk, tl_unused;
+    int d_it = 0, d_kt = 0, d_mblk, tl_unused, d_ring = 0;
     item_of(0, tl_unused, d_mblk);
     auto dma_next = [&]() __attribute__((always_inline)) {
       // past the last item the requests re-read its last K-tile into a ring slot nobody reads any more: the instruction
       // count per iteration stays constant, which is what the counted wait relies on
       const unsigned so = (unsigned)((((size_t)d_mblk * nkt + d_kt) * A_U4) * 16);
-      uint4* dst = ring + (d_kt % 3) * A_U4;
+      uint4* dst = ring + d_ring * A_U4;
+      d_ring = d_ring == RING - 1 ? 0 : d_ring + 1;
 #pragma unroll
       for (int pc = 0; pc < HALF_DMA; ++pc) {
         const int piece = dw_ * HALF_DMA + pc;
@@ -227,16 +235,18 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
       }
     };
-    dma_next();
-    dma_next();
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) dma_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int total = nitems * nkt;
 #pragma unroll 1
     for (int k = 0; k < total; ++k) {
-      if (!(KP_DIAG & 2)) dma_next();                 // K-tile k + 2 -> the slot K-tile k - 1 was read from
+      if (!(KP_DIAG & 2)) dma_next();                 // K-tile k + RING - 1 -> the slot K-tile k - 1 was read from
+      // (counted: everything but the youngest RING - 2 batches has landed = K-tile k + 1 is in LDS)
       if constexpr (HALF_DMA == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       else if constexpr (HALF_DMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -406,7 +416,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int NI = NIF;
   constexpr int XJ0 = decltype(xj0_tag)::value, XJN = decltype(xjn_tag)::value;      // the shared row tile: my column tiles of it
   constexpr int XA = XJN > 0 ? 1 : 0;
-  int pb = 0;
+  int pb = 0, slot3 = 0;
   for (int it = 0; it < nitems; ++it) {
     int tile, mblk;
     item_of(it, tile, mblk);
@@ -481,7 +491,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 
     // one K-tile per call, NOT unrolled over the taps: with the tap a compile-time constant the compiler hoists all
     // 9 x 7 x 2 fragment addresses out of the loop (126 VGPRs) and spills the accumulators
-    int tap = 0, slot3 = 0, dh_pitch = 0, dw = 0;
+    int tap = 0, dh_pitch = 0, dw = 0;                 // (slot3, the ring slot of the next K-tile, runs on across the items)
 #if KP_DIAG & 16
     const bool stamp = blockIdx.x == 0 && wave == 0;
     unsigned long long s_loop = 0, s_bar = 0, s_a = 0;
@@ -547,7 +557,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         // nothing moves across this point: the next group's issue stays behind these products
         __builtin_amdgcn_sched_barrier(0);
       }
-      slot3 = slot3 == 2 ? 0 : slot3 + 1;
+      slot3 = slot3 == RING - 1 ? 0 : slot3 + 1;
       tap = ntap; dw = ndw; dh_pitch = ndh; pb = npb;
 #if KP_DIAG & 16
       const unsigned long long t_b0 = KP_T();

@@ -54,12 +54,13 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int A_U4 = BM * 8;                       // uint4 per packed K-tile
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
   constexpr int P_U4 = KT_ROWS * 8;
-  __shared__ uint4 smem[3 * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
+  constexpr int RING = KP_RING6 && MT == 4 ? 6 : 3;   // weight ring: six K-tiles at 64 rows (igemm_k1p explains)
+  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
   __shared__ __attribute__((aligned(16))) float aff_a[AFF ? 2 * KT_AFFC : 4], aff_b[AFF ? 2 * KT_AFFC : 4];
   uint4* const ring = smem;
-  uint4* const patch = smem + 3 * A_U4;
-  float* const inva_s = reinterpret_cast<float*>(smem + 3 * A_U4 + 2 * P_U4);      // [2][BM], by item parity
-  double* const stat_s = reinterpret_cast<double*>(smem + 3 * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
+  uint4* const patch = smem + RING * A_U4;
+  float* const inva_s = reinterpret_cast<float*>(smem + RING * A_U4 + 2 * P_U4);      // [2][BM], by item parity
+  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -142,22 +143,24 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       for (int piece = 0; piece < A_DMA; ++piece)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
                                                  (unsigned)(lane * 16 + piece * 1024), so, 0, 0);
-      d_ring = d_ring == 2 ? 0 : d_ring + 1;          // (past the last item: the last K-tile again, into slots nobody reads)
+      d_ring = d_ring == RING - 1 ? 0 : d_ring + 1;   // (past the last item: the last K-tile again, into slots nobody reads)
       if (d_it + 1 < nitems || d_kt + 1 < nkt) {
         if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
       }
     };
-    dma_next();
-    dma_next();
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) dma_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int total = nitems * nkt;
     static_assert(A_DMA == 8 || A_DMA == 16 || A_DMA == 18, "the counted wait below lists the piece counts");
 #pragma unroll 1
     for (int k = 0; k < total; ++k) {
-      dma_next();                                     // K-tile k + 2 -> the slot K-tile k - 1 was read from
+      dma_next();                                     // K-tile k + RING - 1 -> the slot K-tile k - 1 was read from
+      // (counted: everything but the youngest RING - 2 batches has landed = K-tile k + 1 is in LDS)
       if constexpr (A_DMA == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
       else if constexpr (A_DMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if constexpr (RING == 6) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -327,7 +330,7 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int NI = NIF;
   constexpr int XJ0 = decltype(xj0_tag)::value, XJN = decltype(xjn_tag)::value;      // the shared row tile: my column tiles of it
   constexpr int XA = XJN > 0 ? 1 : 0;
-  int pb = 0;
+  int pb = 0, slot3 = 0;
   for (int it = 0; it < nitems; ++it) {
     int tile, mblk, nb, d0, hw0;
     item_of(it, tile, mblk);
@@ -368,7 +371,7 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     const int arow0 = (mt0 * 16 + fr) * 8;
     unsigned addr_n = b_addr(2, patch_lds + pb * (P_U4 * 16), 0);
 
-    int tap = 0, slot3 = 0;
+    int tap = 0;                                       // (slot3, the ring slot of the next K-tile, runs on across the items)
     auto ktile = [&](auto ph_tag) __attribute__((always_inline)) {
       constexpr int PH = decltype(ph_tag)::value;        // buffer of this K-tile's column tile 0
       const uint4* Ab = ring + slot3 * A_U4;
@@ -410,7 +413,7 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      slot3 = slot3 == 2 ? 0 : slot3 + 1;
+      slot3 = slot3 == RING - 1 ? 0 : slot3 + 1;
       tap = ntap; pb = npb;
       __builtin_amdgcn_s_barrier();
     };
