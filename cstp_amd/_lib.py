@@ -12,7 +12,7 @@ from ctypes import c_uint32, POINTER, c_char_p, c_double, c_float, c_int32, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class ConvDesc(ctypes.Structure):
@@ -110,6 +110,23 @@ SIGNATURES = {
     "cstp_clip_coef": (c_int32, [_P, _P, c_float, _P, _P]),
     "cstp_sgd_step": (c_int32, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, _P, c_int32, c_int32]),
     "cstp_adam_step": (c_int32, [_P, _P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_int32, c_int32]),
+    # the bf16-storage path (csrc/b16.hip)
+    "cstp_b16_cast": (c_int32, [_P, _P, _P, c_size_t]),
+    "cstp_b16_conv3d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "cstp_b16_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_b16_conv3d_backward_data": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_b16_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, c_int32]),
+    "cstp_b16_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "cstp_b16_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                            c_float, c_float, c_int32, _P, c_size_t]),
+    "cstp_b16_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, _P, c_size_t, c_int32]),
+    "cstp_b16_maxpool3d_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32),
+                                             POINTER(c_int32), POINTER(c_int32)]),
+    "cstp_b16_maxpool3d_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32),
+                                              POINTER(c_int32), POINTER(c_int32)]),
+    "cstp_b16_avgpool_forward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
+    "cstp_b16_avgpool_backward": (c_int32, [_P, _P, _P, c_int32, c_int32]),
 }
 
 _lib = None

@@ -1,0 +1,1090 @@
+// The bf16-STORAGE path (BASELINE configs[4]: "3D-ResNet-50 backbone swap ... bf16"; models/BE/r3d_byol.py:100-206).
+//
+// Spec (the reference has no reduced-precision mode; this is what torch.autocast(bfloat16) does to its modules, stated so that
+// the oracle can restate it -- oracle/r3d_byol_oracle.py `storage="bf16"`):
+//   * every 5-D activation tensor in HBM is bf16: the clip (cast once), convolution outputs, BatchNorm(+residual)(+ReLU) outputs,
+//     MaxPool3d output, and in the backward pass every gradient of such a tensor;
+//   * all arithmetic between a load and a store is fp32 (fp64 inside the BatchNorm reductions); each stored value is the fp32
+//     result rounded to nearest-even ONCE;
+//   * convolution operands are the bf16 activations and the fp32 master weights rounded to bf16 at use
+//     (v_mfma_f32_16x16x32_bf16: exact products, fp32 accumulation -- no operand split, ceiling 2 516 TFLOP/s);
+//   * parameters, their gradients (accumulated in fp32 from the bf16 operands), BatchNorm statistics and running statistics,
+//     the pooled features, predictor / heads / losses, optimizer: fp32 as on the fp32-storage path.
+//
+// Kernels (layout NCDHW, positions contiguous; one wave = 64 lanes):
+//   conv_b16_kernel<MT, TAB>   implicit GEMM, forward AND data gradient: tile = 128 positions x 16*MT channels, K-tile 32,
+//                              X gathered with 2-byte buffer loads (halo = out-of-range offset = 0), both operands through a
+//                              swizzled LDS double buffer, one barrier per K-tile.  TAB: reduction index k = tap * C + c over a
+//                              zero-padded copy with a per-k offset table (the 3-channel 7x7x7 stem).
+//   wgrad_b16_kernel<TAB>      dW[m][k] += sum_p dY[m][p] * Xcol[k][p]: 64 x 64 tile, reduction over 64-position chunks,
+//                              split over the positions, fp32 atomics into the gradient.
+//   BatchNorm / pooling / cast: HBM-streaming, 16-byte (8 x bf16) accesses where rows allow.
+#include "common.h"
+
+namespace cstp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ float bflo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bfhi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+// two fp32 -> packed bf16 pair (element 0 in the low half), round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+  f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ u16 f2bf(float a) { return (u16)(pack_bf2(a, 0.f) & 0xffffu); }
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16_last(const u16* p) {          // streaming (last-use) 16-byte load
+  const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t b16_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+constexpr unsigned B16_OOB = 0x80000000u;      // host guarantees every gathered tensor is < 2 GiB
+constexpr int B16_MAXTAPS = 27;
+constexpr int B16_KTAB = 1056;                 // 7x7x7 taps x 3 channels = 1029, padded to 32
+
+// ---- fp32 -> bf16 ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cast_b16_kernel(const float* __restrict__ x, u16* __restrict__ y, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+}
+
+// zero-padded copy xp[plane][D + 2pt][H + 2ph][W + 2pw] of x[plane][D][H][W] (both bf16): one wave per padded row
+__global__ void __launch_bounds__(256)
+pad_b16_kernel(const u16* __restrict__ x, u16* __restrict__ xp, int planes, int D, int H, int W, int pt, int ph, int pw) {
+  const int Dq = D + 2 * pt, Hq = H + 2 * ph, Wq = W + 2 * pw;
+  const int nrows = planes * Dq * Hq;
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
+    const int h = row % Hq, r2 = row / Hq;
+    const int d = r2 % Dq, pl = r2 / Dq;
+    const int id = d - pt, ih = h - ph;
+    const bool in = (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H;
+    const u16* src = x + ((size_t)(pl * D + (in ? id : 0)) * H + (in ? ih : 0)) * W;
+    u16* dst = xp + (size_t)row * Wq;
+    for (int w = lane; w < Wq; w += 64) {
+      const int iw = w - pw;
+      dst[w] = (in && (unsigned)iw < (unsigned)W) ? src[iw] : (u16)0;
+    }
+  }
+}
+
+// ---- weights: fp32 [kout][cin][taps] -> bf16 GEMM operand rows ------------------------------------------------------------------
+// forward:        wp[m = kout (Mp rows)][k = tap * cin + c  (Kw, zero beyond taps * cin)]
+// data gradient:  wp[m = cin  (Mp rows)][k = tap * kout + ko]
+__global__ void __launch_bounds__(256)
+pack_w_b16_kernel(const float* __restrict__ w, u16* __restrict__ wp, int kout, int cin, int ntaps, int Mp, int Kw, int dgrad) {
+  const size_t total = (size_t)Mp * Kw;
+  const int inner = dgrad ? kout : cin, mreal = dgrad ? cin : kout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kw), m = (int)(i / Kw);
+    const int tap = k / inner, c = k - tap * inner;
+    float v = 0.f;
+    if (m < mreal && tap < ntaps) v = dgrad ? w[((size_t)c * cin + m) * ntaps + tap] : w[((size_t)m * cin + c) * ntaps + tap];
+    wp[i] = f2bf(v);
+  }
+}
+
+// ---- implicit-GEMM convolution, forward and data gradient ---------------------------------------------------------------------
+// out[nb][m][o(q)] = sum over the tap list and the source channels of  W[m][wtap][c] * src[nb][c][q * ss + off(tap)]
+//   forward:        q = output position, ss = stride, off = tap - padding, o(q) = q
+//   data gradient:  one launch per stride-parity class z of the INPUT positions: q enumerates the positions of the class
+//                   (input coordinate = q * stride + z), src = dY, ss = 1, the tap list holds the taps with
+//                   (z + pad - tap) % stride == 0, off = (z + pad - tap) / stride, o(q) = q * stride + z
+struct B16Conv {
+  int Nb, Cs, Ds, Hs, Ws;          // source tensor [Nb][Cs][Ds][Hs][Ws]
+  int Dq, Hq, Wq;                  // enumerated positions per sample
+  int sst, ssh, ssw;               // source coordinate = q * ss + off
+  int M, Do, Ho, Wo;               // output tensor [Nb][M][Do][Ho][Wo]
+  int ost, osh, osw, ozt, ozh, ozw;  // output coordinate = q * os + oz
+  int ntaps;                       // entries of the tap list (grouped mode), or taps of the table mode
+  int Kw;                          // elements per packed weight row
+  int contig;                      // four consecutive q are four consecutive, 8-byte aligned outputs of one sample
+  int n_tiles_x, n_tiles_m;
+  int kh, kw;                      // TAB: kernel extent (for the offset table)
+  short off[B16_MAXTAPS][4];       // per list entry: source offset (t, h, w), weight tap index
+};
+
+// 16-byte chunk c (0..3) of the 64-byte LDS row `row` (32 k of one position / one channel) sits at c ^ ((row >> 2) & 3):
+// the 16 rows x one chunk of a fragment read then cover all 64 banks once.
+__device__ __forceinline__ int b16_slot(int row, int c) { return row * 4 + (c ^ ((row >> 2) & 3)); }
+
+template <int MT, bool TAB>
+__global__ void __launch_bounds__(256)
+conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __restrict__ wp, u16* __restrict__ out) {
+  constexpr int BM = 16 * MT;
+  constexpr int NW = BM / 64;                       // 16-byte weight chunks per thread and K-tile
+  __shared__ uint4 Xs[2][128 * 4];
+  __shared__ uint4 Ws[2][BM * 4];
+  __shared__ int taps[B16_MAXTAPS * 4];
+  __shared__ unsigned ktab[TAB ? B16_KTAB : 4];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // XCD-aware order: the blocks of one XCD (bid & 7) walk the row tiles of one position tile back to back
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mtile = slot % g.n_tiles_m;
+  const int chunk = (g.n_tiles_x + 7) >> 3;
+  const int nt_in = slot / g.n_tiles_m;
+  const int ntile = xcd * chunk + nt_in;
+  if (nt_in >= chunk || ntile >= g.n_tiles_x) return;
+  const int npq = g.Dq * g.Hq * g.Wq;
+  const int npos = g.Nb * npq;
+  const int n0 = ntile * 128, m0 = mtile * BM;
+  const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+
+  if (!TAB) {
+    if (t < g.ntaps * 4) taps[t] = g.off[t >> 2][t & 3];
+  } else {
+    const int khw = g.kh * g.kw, kreal = g.ntaps * g.Cs;
+    for (int k = t; k < g.Kw; k += 256) {
+      const int kk = k < kreal ? k : 0;               // the padding k's carry zero weights: any in-range address will do
+      const int tp = kk / g.Cs, c = kk - tp * g.Cs;
+      const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dw = rr - dh * g.kw;
+      ktab[k] = (unsigned)((c * g.Ds + dt) * HWs + dh * g.Ws + dw) * 2u;
+    }
+  }
+  __syncthreads();
+
+  // ---- my part of the gather: position p, 16-k group g2 of every K-tile
+  const int p = t & 127, g2 = t >> 7;
+  const int P = n0 + p;
+  const bool pvalid = P < npos;
+  int qd, qh, qw, nb;
+  {
+    int n = pvalid ? P : 0;
+    qw = n % g.Wq; n /= g.Wq;
+    qh = n % g.Hq; n /= g.Hq;
+    qd = n % g.Dq; nb = n / g.Dq;
+  }
+  const int cd0 = qd * g.sst, ch0 = qh * g.ssh, cw0 = qw * g.ssw;
+  const unsigned nb_off = (unsigned)((size_t)nb * g.Cs * DHWs);          // elements
+  const unsigned cstride = (unsigned)DHWs * 2u;                         // bytes between channels
+  const __amdgpu_buffer_rsrc_t rs_src = b16_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 2));
+  const int gpt = TAB ? 1 : (g.Cs >> 4);                                // 16-channel groups per tap
+  const int ngroups = TAB ? (g.Kw >> 4) : g.ntaps * gpt;
+  const int ntiles = (ngroups + 1) >> 1;
+  int ti = g2 / gpt, cg = g2 - ti * gpt;                                // (tap entry, channel group) of my group in K-tile 0
+  const unsigned tab_base = (unsigned)(((size_t)nb * g.Cs * g.Ds + cd0) * HWs + ch0 * g.Ws + cw0) * 2u;   // TAB: bytes
+
+  // ---- my part of the weight tile: row wrow (+64), chunk wc of the K-tile (group wc >> 1, half wc & 1)
+  const int wrow = t >> 2, wc = t & 3;
+  const char* wbase = reinterpret_cast<const char*>(wp) + (size_t)(m0 + wrow) * g.Kw * 2;
+  const size_t wrow64 = (size_t)64 * g.Kw * 2;
+
+  u16 xr[16];
+  uint4 wr[NW];
+
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    // X
+    unsigned vo = B16_OOB;
+    if (TAB) {
+      const int k0 = (kt * 2 + g2) * 16;
+      if (pvalid && k0 < g.Kw) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          xr[j] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_src, tab_base + ktab[k0 + j], 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xr[j] = 0;
+      }
+    } else {
+      const int gi = kt * 2 + g2;
+      if (pvalid && gi < ngroups) {
+        const int cd = cd0 + taps[ti * 4 + 0], chh = ch0 + taps[ti * 4 + 1], cw = cw0 + taps[ti * 4 + 2];
+        if ((unsigned)cd < (unsigned)g.Ds && (unsigned)chh < (unsigned)g.Hs && (unsigned)cw < (unsigned)g.Ws)
+          vo = (nb_off + (unsigned)(cg * 16) * (unsigned)DHWs + (unsigned)(cd * HWs + chh * g.Ws + cw)) * 2u;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        xr[j] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_src, vo, (unsigned)j * cstride, 0);
+    }
+    // W
+    int kel;                                                            // element offset of my chunk inside the packed row
+    bool wok;
+    if (TAB) {
+      kel = kt * 32 + wc * 8;
+      wok = kel < g.Kw;
+    } else {
+      const int gi = kt * 2 + (wc >> 1);
+      wok = gi < ngroups;
+      const int wti = wok ? gi / gpt : 0, wcg = gi - wti * gpt;
+      kel = taps[wti * 4 + 3] * g.Cs + wcg * 16 + (wc & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      wr[j] = make_uint4(0, 0, 0, 0);
+      if (wok) wr[j] = *reinterpret_cast<const uint4*>(wbase + j * wrow64 + (size_t)kel * 2);
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    if (!TAB) {
+      cg += 2;
+      while (cg >= gpt) { cg -= gpt; ++ti; }
+    }
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    uint4 a, b;
+    a.x = xr[0] | ((unsigned)xr[1] << 16); a.y = xr[2] | ((unsigned)xr[3] << 16);
+    a.z = xr[4] | ((unsigned)xr[5] << 16); a.w = xr[6] | ((unsigned)xr[7] << 16);
+    b.x = xr[8] | ((unsigned)xr[9] << 16); b.y = xr[10] | ((unsigned)xr[11] << 16);
+    b.z = xr[12] | ((unsigned)xr[13] << 16); b.w = xr[14] | ((unsigned)xr[15] << 16);
+    Xs[buf][b16_slot(p, g2 * 2)] = a;
+    Xs[buf][b16_slot(p, g2 * 2 + 1)] = b;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) Ws[buf][b16_slot(wrow + 64 * j, wc)] = wr[j];
+  };
+
+  f32x4 acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  advance();
+  stage(0);
+  __syncthreads();
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) { issue(kt + 1); advance(); }
+    bf16x8 xa[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = wave * 32 + a * 16 + frow;
+      xa[a] = __builtin_bit_cast(bf16x8, Xs[buf][b16_slot(row, fchunk)]);
+    }
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      const int row = b * 16 + frow;
+      const bf16x8 wb = __builtin_bit_cast(bf16x8, Ws[buf][b16_slot(row, fchunk)]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a], wb, acc[a][b], 0, 0, 0);
+    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds positions 4 * (lane >> 4) + r (r = 0..3) of position tile a, channel (lane & 15) of row tile b
+  const int DHWo = g.Do * g.Ho * g.Wo, HWo = g.Ho * g.Wo;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int P0 = n0 + wave * 32 + a * 16 + 4 * (lane >> 4);
+    if (g.contig) {
+      if (P0 >= npos) continue;
+      const int nbo = P0 / npq, pos = P0 - nbo * npq;
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int m = m0 + b * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        const f32x4 v = acc[a][b];
+        *reinterpret_cast<uint2*>(out + ((size_t)nbo * g.M + m) * DHWo + pos) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    } else {
+      size_t ooff[4];
+      bool ok[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = P0 + r;
+        ok[r] = n < npos;
+        n = ok[r] ? n : 0;
+        const int w_ = n % g.Wq; n /= g.Wq;
+        const int h_ = n % g.Hq; n /= g.Hq;
+        const int d_ = n % g.Dq; const int nbo = n / g.Dq;
+        ooff[r] = (size_t)nbo * g.M * DHWo + (size_t)(d_ * g.ost + g.ozt) * HWo + (h_ * g.osh + g.ozh) * g.Wo + (w_ * g.osw + g.ozw);
+      }
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int m = m0 + b * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        const f32x4 v = acc[a][b];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ok[r]) out[ooff[r] + (size_t)m * DHWo] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------------
+struct B16Wgrad {
+  int Nb, Cs, Ds, Hs, Ws;          // x (or its zero-padded copy, TAB) [Nb][Cs][Ds][Hs][Ws]
+  int M, Do, Ho, Wo;               // dY [Nb][M][Do][Ho][Wo]
+  int st, sh, sw;                  // source coordinate = o * s + off(tap)
+  int ntaps, K;                    // columns: k = tap * Cs + c, K = ntaps * Cs
+  int vec8;                        // Do*Ho*Wo % 8 == 0: eight consecutive positions of a dY row are one aligned 16-byte load
+  int nchunks, chunks_per_split;   // 64-position chunks
+  int kh, kw;
+  short off[B16_MAXTAPS][4];
+};
+
+constexpr int WG_ROW = 9;          // uint4 per LDS row: 64 positions x 2 B + 16 B padding (fragment reads conflict-free)
+
+template <bool TAB>
+__global__ void __launch_bounds__(256)
+wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ dw) {
+  __shared__ uint4 Ys[2][64 * WG_ROW];
+  __shared__ uint4 Xs[2][64 * WG_ROW];
+  __shared__ int taps[B16_MAXTAPS * 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const int c_lo = blockIdx.z * g.chunks_per_split;
+  int c_hi = c_lo + g.chunks_per_split;
+  c_hi = c_hi < g.nchunks ? c_hi : g.nchunks;
+  if (c_lo >= c_hi) return;
+  if (!TAB && t < g.ntaps * 4) taps[t] = g.off[t >> 2][t & 3];
+  __syncthreads();
+  const int npo = g.Do * g.Ho * g.Wo, npos = g.Nb * npo;
+  const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
+  const __amdgpu_buffer_rsrc_t rs_x = b16_rsrc(x, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 2));
+  const unsigned cstride = (unsigned)DHWs * 2u;
+
+  // X: thread (p, kq) gathers the 16 columns k0 + 16 kq + j of position p
+  const int p = t & 63, kq = t >> 6;
+  const int gpt = TAB ? 1 : (g.Cs >> 4);
+  const int gi = (k0 >> 4) + kq;
+  const bool gvalid = TAB ? true : gi < g.ntaps * gpt;
+  const int ti = gvalid ? gi / gpt : 0, c0 = (gi - ti * gpt) * 16;
+  int toff[3] = {0, 0, 0};
+  if (!TAB) { toff[0] = taps[ti * 4]; toff[1] = taps[ti * 4 + 1]; toff[2] = taps[ti * 4 + 2]; }
+  unsigned ktb[16];
+  if (TAB) {
+    const int khw = g.kh * g.kw;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int k = k0 + kq * 16 + j;
+      k = k < g.K ? k : 0;
+      const int tp = k / g.Cs, c = k - tp * g.Cs;
+      const int dt = tp / khw, rr = tp - dt * khw, dh = rr / g.kw, dwv = rr - dh * g.kw;
+      ktb[j] = (unsigned)((c * g.Ds + dt) * HWs + dh * g.Ws + dwv) * 2u;
+    }
+  }
+  // dY: thread (row, two octets)
+  const int yrow = t >> 2, yo = (t & 3) * 2;
+  const bool mvalid = m0 + yrow < g.M;
+
+  u16 xr[16];
+  uint4 yr[2];
+  auto issue = [&](int ci) __attribute__((always_inline)) {
+    const int P0 = ci * 64;
+    {
+      int n = P0 + p;
+      const bool pv = n < npos && gvalid;
+      n = pv ? n : 0;
+      const int ow = n % g.Wo; n /= g.Wo;
+      const int oh = n % g.Ho; n /= g.Ho;
+      const int od = n % g.Do; const int nb = n / g.Do;
+      if (TAB) {
+        const unsigned base = (unsigned)(((size_t)nb * g.Cs * g.Ds + od * g.st) * HWs + oh * g.sh * g.Ws + ow * g.sw) * 2u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          xr[j] = pv ? (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_x, base + ktb[j], 0, 0) : (u16)0;
+      } else {
+        unsigned vo = B16_OOB;
+        const int cd = od * g.st + toff[0], chh = oh * g.sh + toff[1], cw = ow * g.sw + toff[2];
+        if (pv && (unsigned)cd < (unsigned)g.Ds && (unsigned)chh < (unsigned)g.Hs && (unsigned)cw < (unsigned)g.Ws)
+          vo = (unsigned)(((size_t)nb * g.Cs + c0) * DHWs + cd * HWs + chh * g.Ws + cw) * 2u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xr[j] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs_x, vo, (unsigned)j * cstride, 0);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int Pq = P0 + (yo + o) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (mvalid && Pq < npos) {
+        const int nb = Pq / npo, pos = Pq - nb * npo;
+        const u16* rowp = dy + ((size_t)nb * g.M + m0 + yrow) * npo + pos;
+        if (g.vec8) {
+          v = *reinterpret_cast<const uint4*>(rowp);
+        } else {
+          unsigned e[8];
+          int nbb = nb, pp = pos;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            e[j] = (Pq + j < npos) ? dy[((size_t)nbb * g.M + m0 + yrow) * npo + pp] : 0;
+            if (++pp == npo) { pp = 0; ++nbb; }
+          }
+          v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+      }
+      yr[o] = v;
+    }
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    u16* xs = reinterpret_cast<u16*>(&Xs[buf][0]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xs[(kq * 16 + j) * (WG_ROW * 8) + p] = xr[j];
+    Ys[buf][yrow * WG_ROW + yo] = yr[0];
+    Ys[buf][yrow * WG_ROW + yo + 1] = yr[1];
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mt0 = (wave >> 1) * 2, nt0 = (wave & 1) * 2;
+  const int frow = lane & 15, fchunk = lane >> 4;
+
+  issue(c_lo);
+  stage(0);
+  __syncthreads();
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    const int buf = (ci - c_lo) & 1;
+    const bool more = ci + 1 < c_hi;
+    if (more) issue(ci + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ya[2], xb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) ya[a] = __builtin_bit_cast(bf16x8, Ys[buf][((mt0 + a) * 16 + frow) * WG_ROW + ks * 4 + fchunk]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) xb[b] = __builtin_bit_cast(bf16x8, Xs[buf][((nt0 + b) * 16 + frow) * WG_ROW + ks * 4 + fchunk]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[a], xb[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds rows m = 4 * (lane >> 4) + r of row tile a, column (lane & 15) of column tile b
+  const int ntaps_w = TAB ? g.ntaps : g.kh;       // grouped mode: kh carries the layer's total tap count
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = (nt0 + b) * 16 + (lane & 15);
+    int c, wtap;
+    bool cok;
+    if (TAB) {
+      const int k = k0 + col;
+      cok = k < g.K;
+      wtap = k / g.Cs;
+      c = k - wtap * g.Cs;
+    } else {
+      const int gj = (k0 >> 4) + (col >> 4);
+      cok = gj < g.ntaps * gpt;
+      const int tj = cok ? gj / gpt : 0;
+      c = (gj - tj * gpt) * 16 + (col & 15);
+      wtap = taps[tj * 4 + 3];
+    }
+    if (!cok) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (mt0 + a) * 16 + 4 * (lane >> 4) + r;
+        if (m < g.M) atomicAdd(dw + ((size_t)m * g.Cs + c) * ntaps_w + wtap, acc[a][b][r]);
+      }
+    }
+  }
+}
+
+// ---- train-mode BatchNorm (+ residual) (+ ReLU) on bf16 tensors: fp64 statistics, fp32 apply ------------------------------------
+static inline int b16_bn_nsplit(int n, int c) {
+  int ns = cdiv(2048, c);
+  if (ns > n) ns = n;
+  return ns < 1 ? 1 : ns;
+}
+
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g * xhat), g = dy * mask
+template <int MODE, bool VEC8>
+__global__ void __launch_bounds__(256)
+b16_bn_reduce_kernel(const u16* __restrict__ x, const u16* __restrict__ y, const u16* __restrict__ dy, const float* __restrict__ mean,
+                     const float* __restrict__ invstd, double* __restrict__ part, int npg, int c, int s, int nsplit, int relu,
+                     const float2* __restrict__ ss) {
+  __shared__ double sm[16];
+  const int ch = blockIdx.x, grp = blockIdx.y / nsplit, j = blockIdx.y - grp * nsplit;
+  double a0 = 0.0, a1 = 0.0;
+  float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+  if (MODE == 1) { mu = mean[grp * c + ch]; is = invstd[grp * c + ch]; }
+  const bool remask = (MODE == 1) && relu && (y == nullptr);
+  if (remask) { const float2 t2 = ss[grp * c + ch]; sc = t2.x; sh = t2.y; }
+  auto one = [&](float v, float gq, float o) __attribute__((always_inline)) {
+    if (MODE == 0) {
+      a0 += (double)v; a1 += (double)v * v;
+    } else {
+      if (remask) { if (!(__builtin_fmaf(v, sc, sh) > 0.f)) gq = 0.f; }
+      else if (relu && !(o > 0.f)) gq = 0.f;
+      a0 += (double)gq; a1 += (double)(gq * ((v - mu) * is));
+    }
+  };
+  for (int rr = j; rr < npg; rr += nsplit) {
+    const size_t base = ((size_t)(grp * npg + rr) * c + ch) * s;
+    if (VEC8) {
+      const uint4* xp = reinterpret_cast<const uint4*>(x + base);
+      const uint4* gp = reinterpret_cast<const uint4*>(dy + base);
+      const uint4* yp = reinterpret_cast<const uint4*>(y + base);
+      for (int i = threadIdx.x; i < (s >> 3); i += 256) {
+        const uint4 v = xp[i];
+        uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+        if (MODE == 1) { gv = gp[i]; if (relu && !remask) ov = yp[i]; }
+        const unsigned vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { one(bflo(vv[e]), bflo(gg[e]), bflo(oo[e])); one(bfhi(vv[e]), bfhi(gg[e]), bfhi(oo[e])); }
+      }
+    } else {
+      for (int i = threadIdx.x; i < s; i += 256)
+        one(bf2f(x[base + i]), MODE == 1 ? bf2f(dy[base + i]) : 0.f, (MODE == 1 && relu && !remask) ? bf2f(y[base + i]) : 0.f);
+    }
+  }
+  a0 = block_sum(a0, sm);
+  a1 = block_sum(a1, sm);
+  if (threadIdx.x == 0) {
+    part[((size_t)ch * gridDim.y + blockIdx.y) * 2 + 0] = a0;
+    part[((size_t)ch * gridDim.y + blockIdx.y) * 2 + 1] = a1;
+  }
+}
+
+__global__ void b16_bn_finalize_fwd_kernel(const double* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                           float* __restrict__ running_mean, float* __restrict__ running_var, int c, int groups,
+                                           int nsplit, double count, float eps, float momentum, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float2* __restrict__ ss) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float rm = 0.f, rv = 0.f;
+  if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    save_mean[g * c + ch] = (float)mu;
+    const float isf = (float)(1.0 / sqrt(var + (double)eps));
+    save_invstd[g * c + ch] = isf;
+    const float scl = isf * gamma[ch];
+    ss[g * c + ch] = make_float2(scl, beta[ch] - (float)mu * scl);
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
+    rv = (float)((1.0 - momentum) * rv + momentum * unb);
+  }
+  if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+}
+
+__global__ void b16_bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                           float* __restrict__ gsum, int c, int groups, int nsplit, int accumulate) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+    gsum[(g * c + ch) * 2 + 0] = (float)s0;
+    gsum[(g * c + ch) * 2 + 1] = (float)s1;
+    t0 += s0; t1 += s1;
+  }
+  dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+  dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
+}
+
+constexpr int B16_UNROLL = 4;     // 16-byte vectors per thread per block
+
+// y = bf16(act(fma(x, scale, shift) + residual)); one block = one chunk of one (sample, channel) row
+template <bool VEC8>
+__global__ void __launch_bounds__(256)
+b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, u16* __restrict__ y, const float2* __restrict__ ss,
+                        int c, int s, int npg, int relu, int chunks) {
+  constexpr int W = VEC8 ? 8 : 1;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const float2 t2 = ss[gc];
+  const float sc = t2.x, sh = t2.y;
+  const size_t base = (size_t)row * s;
+#pragma unroll
+  for (int u = 0; u < B16_UNROLL; ++u) {
+    const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    if (e >= s) continue;
+    if (VEC8) {
+      const uint4 v = ld16_last(x + base + e);
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (res != nullptr) r = *reinterpret_cast<const uint4*>(res + base + e);
+      const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = __builtin_fmaf(bflo(vv[q]), sc, sh) + bflo(rr[q]), b = __builtin_fmaf(bfhi(vv[q]), sc, sh) + bfhi(rr[q]);
+        if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+        o[q] = pack_bf2(a, b);
+      }
+      *reinterpret_cast<uint4*>(y + base + e) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      float a = __builtin_fmaf(bf2f(x[base + e]), sc, sh);
+      if (res != nullptr) a += bf2f(res[base + e]);
+      if (relu) a = fmaxf(a, 0.f);
+      y[base + e] = f2bf(a);
+    }
+  }
+}
+
+// dx = bf16(gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))), dres = bf16(g), g = dy * mask
+template <bool VEC8>
+__global__ void __launch_bounds__(256)
+b16_bn_apply_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, const u16* __restrict__ dy, const float* __restrict__ gamma,
+                        const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gsum,
+                        u16* __restrict__ dx, u16* __restrict__ dres, int c, int s, int npg, float inv_count, int relu,
+                        const float2* __restrict__ ss, int chunks) {
+  constexpr int W = VEC8 ? 8 : 1;
+  const bool remask = relu && (y == nullptr);
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const float mu = mean[gc], is = invstd[gc];
+  const float k = gamma[ch] * is;
+  const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
+  float sc = 0.f, sh = 0.f;
+  if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
+  const size_t base = (size_t)row * s;
+  auto one = [&](float v, float gq, float o, float& gout) __attribute__((always_inline)) -> float {
+    if (remask) { if (!(__builtin_fmaf(v, sc, sh) > 0.f)) gq = 0.f; }
+    else if (relu && !(o > 0.f)) gq = 0.f;
+    gout = gq;
+    return k * (gq - mb - (v - mu) * is * mg);
+  };
+#pragma unroll
+  for (int u = 0; u < B16_UNROLL; ++u) {
+    const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    if (e >= s) continue;
+    if (VEC8) {
+      const uint4 v = ld16_last(x + base + e);
+      const uint4 gv = ld16_last(dy + base + e);
+      uint4 ov = make_uint4(0, 0, 0, 0);
+      if (relu && !remask) ov = *reinterpret_cast<const uint4*>(y + base + e);
+      const unsigned vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
+      unsigned o[4], gr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float g0, g1;
+        const float a = one(bflo(vv[q]), bflo(gg[q]), bflo(oo[q]), g0), b = one(bfhi(vv[q]), bfhi(gg[q]), bfhi(oo[q]), g1);
+        o[q] = pack_bf2(a, b);
+        gr[q] = pack_bf2(g0, g1);
+      }
+      *reinterpret_cast<uint4*>(dx + base + e) = make_uint4(o[0], o[1], o[2], o[3]);
+      if (dres != nullptr) *reinterpret_cast<uint4*>(dres + base + e) = make_uint4(gr[0], gr[1], gr[2], gr[3]);
+    } else {
+      float g0;
+      const float a = one(bf2f(x[base + e]), bf2f(dy[base + e]), (relu && !remask) ? bf2f(y[base + e]) : 0.f, g0);
+      dx[base + e] = f2bf(a);
+      if (dres != nullptr) dres[base + e] = f2bf(g0);
+    }
+  }
+}
+
+// ---- pooling ------------------------------------------------------------------------------------------------------------------
+// MaxPool3d (models/BE/r3d_byol.py:158): as maxpool3d_fwd/bwd_kernel of misc.hip on bf16 values (comparisons are exact)
+__global__ void b16_maxpool3d_fwd_kernel(const u16* __restrict__ x, u16* __restrict__ y, int32_t* __restrict__ idx, int rows, int D, int H,
+                                         int W, int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph,
+                                         int pw) {
+  const size_t total = (size_t)rows * Do * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int dd = (int)(r % Do); const size_t row = r / Do;
+    const u16* xp = x + row * (size_t)D * H * W;
+    float best = -INFINITY;
+    u16 bb = 0xff80;     // -inf
+    int bi = -1;
+    for (int a = 0; a < kd; ++a) {
+      const int id = dd * sd - pd + a;
+      if ((unsigned)id >= (unsigned)D) continue;
+      for (int b = 0; b < kh; ++b) {
+        const int ih = ho * sh - ph + b;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int c = 0; c < kw; ++c) {
+          const int iw = wo * sw - pw + c;
+          if ((unsigned)iw >= (unsigned)W) continue;
+          const int fi = (id * H + ih) * W + iw;
+          const u16 raw = xp[fi];
+          const float v = bf2f(raw);
+          if (v > best || v != v || bi < 0) { best = v; bb = raw; bi = fi; }
+        }
+      }
+    }
+    y[i] = bb;
+    idx[i] = bi;
+  }
+}
+
+__global__ void b16_maxpool3d_bwd_kernel(const u16* __restrict__ dy, const int32_t* __restrict__ idx, u16* __restrict__ dx, int rows, int D,
+                                         int H, int W, int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh, int sw, int pd,
+                                         int ph, int pw) {
+  const size_t total = (size_t)rows * D * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D); const size_t row = r / D;
+    const int fi = (d * H + h) * W + w;
+    const int d_lo = (d + pd - kd + sd) > 0 ? (d + pd - kd + sd) / sd : 0, d_hi = (d + pd) / sd < Do - 1 ? (d + pd) / sd : Do - 1;
+    const int h_lo = (h + ph - kh + sh) > 0 ? (h + ph - kh + sh) / sh : 0, h_hi = (h + ph) / sh < Ho - 1 ? (h + ph) / sh : Ho - 1;
+    const int w_lo = (w + pw - kw + sw) > 0 ? (w + pw - kw + sw) / sw : 0, w_hi = (w + pw) / sw < Wo - 1 ? (w + pw) / sw : Wo - 1;
+    const size_t obase = row * (size_t)Do * Ho * Wo;
+    float acc = 0.f;
+    for (int a = d_lo; a <= d_hi; ++a)
+      for (int b = h_lo; b <= h_hi; ++b)
+        for (int c = w_lo; c <= w_hi; ++c) {
+          const size_t o = obase + ((size_t)a * Ho + b) * Wo + c;
+          if (idx[o] == fi) acc += bf2f(dy[o]);
+        }
+    dx[i] = f2bf(acc);
+  }
+}
+
+// AdaptiveAvgPool3d(1): bf16 rows -> fp32 means (one wave per row); backward fp32 dy -> bf16 dx
+__global__ void b16_avgpool_fwd_kernel(const u16* __restrict__ x, float* __restrict__ y, int rows, int s) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const u16* p = x + (size_t)row * s;
+  float a = 0.f;
+  for (int i = lane; i < s; i += 64) a += bf2f(p[i]);
+  a = wave_sum(a);
+  if (lane == 0) y[row] = a / (float)s;
+}
+
+__global__ void b16_avgpool_bwd_kernel(const float* __restrict__ dy, u16* __restrict__ dx, int rows, int s) {
+  const size_t total = (size_t)rows * s;
+  const float inv = 1.f / (float)s;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dx[i] = f2bf(dy[i / s] * inv);
+}
+
+}  // namespace cstp
+
+using namespace cstp;
+
+static inline unsigned b16_grid(size_t n, int per_block) {
+  size_t b = (n + per_block - 1) / per_block;
+  if (b > 65536) b = 65536;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+struct B16Geom {
+  int Do, Ho, Wo, ntaps;
+  bool tab;       // reduction over a zero-padded copy with an offset table: channel counts that are not multiples of 16
+  int Kw, Dp, Hp, Wp;
+};
+
+static bool b16_geom(const cstp_conv_desc* d, B16Geom& q) {
+  if (d == nullptr || d->n <= 0 || d->c <= 0 || d->k <= 0 || d->kt <= 0 || d->kh <= 0 || d->kw <= 0 || d->st <= 0 || d->sh <= 0 ||
+      d->sw <= 0 || d->pt < 0 || d->ph < 0 || d->pw < 0)
+    return false;
+  q.Do = (d->d + 2 * d->pt - d->kt) / d->st + 1;
+  q.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
+  q.Wo = (d->w + 2 * d->pw - d->kw) / d->sw + 1;
+  if (q.Do <= 0 || q.Ho <= 0 || q.Wo <= 0) return false;
+  q.ntaps = d->kt * d->kh * d->kw;
+  q.tab = (d->c % 16) != 0;
+  q.Dp = d->d + 2 * d->pt; q.Hp = d->h + 2 * d->ph; q.Wp = d->w + 2 * d->pw;
+  q.Kw = q.tab ? (int)align_up((size_t)q.ntaps * d->c, 32) : q.ntaps * d->c;
+  return true;
+}
+
+static size_t b16_pad_bytes(const cstp_conv_desc* d, const B16Geom& q) {
+  return q.tab ? align_up((size_t)d->n * d->c * q.Dp * q.Hp * q.Wp * 2, 256) : 0;
+}
+
+extern "C" size_t cstp_b16_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
+  B16Geom q;
+  if (!b16_geom(desc, q)) return 0;
+  const size_t mp_f = align_up((size_t)desc->k, 128), mp_d = align_up((size_t)desc->c, 128);
+  const size_t wf = align_up(mp_f * q.Kw * 2, 256), wd = align_up(mp_d * (size_t)q.ntaps * desc->k * 2, 256);
+  return (wf > wd ? wf : wd) + b16_pad_bytes(desc, q) + 256;
+}
+
+extern "C" int cstp_b16_cast(void* stream, const float* x, uint16_t* y, size_t n) {
+  CSTP_REQUIRE(x && y && n > 0, "bad argument");
+  CSTP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "cast: unaligned tensor");
+  hipLaunchKernelGGL(cast_b16_kernel, dim3(b16_grid(n / 4 + 1, 256 * 4)), dim3(256), 0, as_stream(stream), x, y, n);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool TAB>
+static void b16_launch_conv(hipStream_t st, const B16Conv& g, int M, const uint16_t* src, const void* wp, uint16_t* out) {
+  const int chunk = (g.n_tiles_x + 7) / 8;
+  const unsigned blocks = (unsigned)(8 * chunk * g.n_tiles_m);
+  if (M > 64)
+    hipLaunchKernelGGL((conv_b16_kernel<8, TAB>), dim3(blocks), dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out);
+  else
+    hipLaunchKernelGGL((conv_b16_kernel<4, TAB>), dim3(blocks), dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out);
+}
+
+extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, const uint16_t* x, const float* w, uint16_t* y, void* ws,
+                                       size_t ws_bytes) {
+  B16Geom q;
+  CSTP_REQUIRE(b16_geom(d, q), "bad convolution geometry");
+  CSTP_REQUIRE(x && w && y && ws && ws_bytes >= cstp_b16_conv3d_workspace_bytes(d), "null argument or workspace too small");
+  CSTP_REQUIRE(q.tab || q.ntaps <= B16_MAXTAPS, "bf16 path: at most 27 filter taps for channel counts that are multiples of 16");
+  CSTP_REQUIRE(!q.tab || q.Kw <= B16_KTAB, "bf16 path: reduction too long for the offset table");
+  CSTP_REQUIRE((size_t)d->n * d->c * q.Dp * q.Hp * q.Wp * 2 < (1ull << 31), "bf16 path: gathered tensor must be < 2 GiB");
+  CSTP_REQUIRE((reinterpret_cast<uintptr_t>(y) & 7) == 0, "unaligned output");
+  hipStream_t st = as_stream(stream);
+  const int BM = d->k > 64 ? 128 : 64;
+  const int Mp = (int)align_up((size_t)d->k, BM);
+  u16* wp = reinterpret_cast<u16*>(ws);
+  hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * q.Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
+  CSTP_LAUNCH_CHECK();
+  B16Conv g;
+  memset(&g, 0, sizeof(g));
+  g.Nb = d->n; g.Cs = d->c;
+  g.Dq = q.Do; g.Hq = q.Ho; g.Wq = q.Wo;
+  g.sst = d->st; g.ssh = d->sh; g.ssw = d->sw;
+  g.M = d->k; g.Do = q.Do; g.Ho = q.Ho; g.Wo = q.Wo;
+  g.ost = g.osh = g.osw = 1;
+  g.Kw = q.Kw;
+  g.contig = ((q.Do * q.Ho * q.Wo) % 4) == 0;
+  g.n_tiles_x = cdiv(d->n * q.Do * q.Ho * q.Wo, 128);
+  g.n_tiles_m = Mp / BM;
+  g.kh = d->kh; g.kw = d->kw;
+  g.ntaps = q.ntaps;
+  if (q.tab) {
+    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + align_up((size_t)align_up((size_t)d->k, 128) * q.Kw * 2, 256));
+    hipLaunchKernelGGL(pad_b16_kernel, dim3(b16_grid((size_t)d->n * d->c * q.Dp * q.Hp, 4)), dim3(256), 0, st, x, xp, d->n * d->c, d->d,
+                       d->h, d->w, d->pt, d->ph, d->pw);
+    CSTP_LAUNCH_CHECK();
+    g.Ds = q.Dp; g.Hs = q.Hp; g.Ws = q.Wp;
+    b16_launch_conv<true>(st, g, d->k, xp, wp, y);
+  } else {
+    g.Ds = d->d; g.Hs = d->h; g.Ws = d->w;
+    int i = 0;
+    for (int a = 0; a < d->kt; ++a)
+      for (int b = 0; b < d->kh; ++b)
+        for (int c = 0; c < d->kw; ++c, ++i) {
+          g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
+        }
+    b16_launch_conv<false>(st, g, d->k, x, wp, y);
+  }
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc* d, const uint16_t* dy, const float* w, uint16_t* dx,
+                                             void* ws, size_t ws_bytes) {
+  B16Geom q;
+  CSTP_REQUIRE(b16_geom(d, q), "bad convolution geometry");
+  CSTP_REQUIRE(dy && w && dx && ws && ws_bytes >= cstp_b16_conv3d_workspace_bytes(d), "null argument or workspace too small");
+  CSTP_REQUIRE((d->k % 16) == 0 && q.ntaps <= B16_MAXTAPS, "bf16 data gradient: output channels a multiple of 16, at most 27 taps");
+  CSTP_REQUIRE((size_t)d->n * d->k * q.Do * q.Ho * q.Wo * 2 < (1ull << 31), "bf16 path: gathered tensor must be < 2 GiB");
+  CSTP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7) == 0, "unaligned output");
+  hipStream_t st = as_stream(stream);
+  const int BM = d->c > 64 ? 128 : 64;
+  const int Mp = (int)align_up((size_t)d->c, BM);
+  const int Kw = q.ntaps * d->k;
+  u16* wp = reinterpret_cast<u16*>(ws);
+  hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, Kw, 1);
+  CSTP_LAUNCH_CHECK();
+  for (int zt = 0; zt < d->st; ++zt)
+    for (int zh = 0; zh < d->sh; ++zh)
+      for (int zw = 0; zw < d->sw; ++zw) {
+        B16Conv g;
+        memset(&g, 0, sizeof(g));
+        g.Nb = d->n; g.Cs = d->k; g.Ds = q.Do; g.Hs = q.Ho; g.Ws = q.Wo;
+        g.Dq = (d->d - zt + d->st - 1) / d->st; g.Hq = (d->h - zh + d->sh - 1) / d->sh; g.Wq = (d->w - zw + d->sw - 1) / d->sw;
+        if (g.Dq <= 0 || g.Hq <= 0 || g.Wq <= 0) continue;
+        g.sst = g.ssh = g.ssw = 1;
+        g.M = d->c; g.Do = d->d; g.Ho = d->h; g.Wo = d->w;
+        g.ost = d->st; g.osh = d->sh; g.osw = d->sw; g.ozt = zt; g.ozh = zh; g.ozw = zw;
+        g.Kw = Kw;
+        g.contig = (d->st == 1 && d->sh == 1 && d->sw == 1 && ((d->d * d->h * d->w) % 4) == 0) ? 1 : 0;
+        g.n_tiles_x = cdiv(d->n * g.Dq * g.Hq * g.Wq, 128);
+        g.n_tiles_m = Mp / BM;
+        g.kh = d->kh; g.kw = d->kw;
+        int i = 0, tp = 0;
+        for (int a = 0; a < d->kt; ++a)
+          for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c, ++tp) {
+              const int et = zt + d->pt - a, eh = zh + d->ph - b, ew = zw + d->pw - c;
+              if ((et % d->st) != 0 || (eh % d->sh) != 0 || (ew % d->sw) != 0) continue;
+              g.off[i][0] = (short)(et / d->st); g.off[i][1] = (short)(eh / d->sh); g.off[i][2] = (short)(ew / d->sw); g.off[i][3] = (short)tp;
+              ++i;
+            }
+        g.ntaps = i;
+        b16_launch_conv<false>(st, g, d->c, dy, wp, dx);
+        CSTP_LAUNCH_CHECK();
+      }
+  return 0;
+}
+
+extern "C" int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw,
+                                               void* ws, size_t ws_bytes, int32_t accumulate) {
+  B16Geom q;
+  CSTP_REQUIRE(b16_geom(d, q), "bad convolution geometry");
+  CSTP_REQUIRE(x && dy && dw && ws && ws_bytes >= cstp_b16_conv3d_workspace_bytes(d), "null argument or workspace too small");
+  CSTP_REQUIRE(q.tab || q.ntaps <= B16_MAXTAPS, "bf16 path: at most 27 filter taps for channel counts that are multiples of 16");
+  CSTP_REQUIRE((size_t)d->n * d->c * q.Dp * q.Hp * q.Wp * 2 < (1ull << 31), "bf16 path: gathered tensor must be < 2 GiB");
+  hipStream_t st = as_stream(stream);
+  if (!accumulate) {
+    if (hipMemsetAsync(dw, 0, (size_t)d->k * d->c * q.ntaps * sizeof(float), st) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+  }
+  B16Wgrad g;
+  memset(&g, 0, sizeof(g));
+  g.Nb = d->n; g.Cs = d->c;
+  g.M = d->k; g.Do = q.Do; g.Ho = q.Ho; g.Wo = q.Wo;
+  g.st = d->st; g.sh = d->sh; g.sw = d->sw;
+  g.ntaps = q.ntaps; g.K = q.ntaps * d->c;
+  const int npo = q.Do * q.Ho * q.Wo;
+  g.vec8 = ((npo % 8) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) ? 1 : 0;
+  g.nchunks = cdiv(d->n * npo, 64);
+  const int tiles = cdiv(g.K, 64) * cdiv(d->k, 64);
+  int S = cdiv(2048, tiles);
+  if (S > g.nchunks) S = g.nchunks;
+  if (S < 1) S = 1;
+  g.chunks_per_split = cdiv(g.nchunks, S);
+  S = cdiv(g.nchunks, g.chunks_per_split);
+  const dim3 grid(cdiv(g.K, 64), cdiv(d->k, 64), S);
+  if (q.tab) {
+    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + align_up((size_t)align_up((size_t)d->k, 128) * q.Kw * 2, 256));
+    hipLaunchKernelGGL(pad_b16_kernel, dim3(b16_grid((size_t)d->n * d->c * q.Dp * q.Hp, 4)), dim3(256), 0, st, x, xp, d->n * d->c, d->d,
+                       d->h, d->w, d->pt, d->ph, d->pw);
+    CSTP_LAUNCH_CHECK();
+    g.Ds = q.Dp; g.Hs = q.Hp; g.Ws = q.Wp;
+    g.kh = d->kh; g.kw = d->kw;
+    hipLaunchKernelGGL((wgrad_b16_kernel<true>), grid, dim3(256), 0, st, g, xp, dy, dw);
+  } else {
+    g.Ds = d->d; g.Hs = d->h; g.Ws = d->w;
+    g.kh = q.ntaps;                  // grouped mode: the layer's total tap count (the weight layout's innermost extent)
+    int i = 0;
+    for (int a = 0; a < d->kt; ++a)
+      for (int b = 0; b < d->kh; ++b)
+        for (int c = 0; c < d->kw; ++c, ++i) {
+          g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
+        }
+    hipLaunchKernelGGL((wgrad_b16_kernel<false>), grid, dim3(256), 0, st, g, x, dy, dw);
+  }
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- BatchNorm --------------------------------------------------------------------------------------------------------------------
+extern "C" size_t cstp_b16_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups) {
+  (void)s;
+  if (n <= 0 || c <= 0 || groups <= 0 || (n % groups) != 0) return 0;
+  // [c][groups][nsplit][2] fp64 partials, then [groups][c][2] fp32 per-group backward sums
+  return align_up((size_t)c * groups * b16_bn_nsplit(n / groups, c) * 2 * sizeof(double), 256) + align_up((size_t)groups * c * 2 * sizeof(float), 256);
+}
+
+extern "C" int cstp_b16_bn_forward_train(void* stream, const uint16_t* x, const uint16_t* residual, uint16_t* y, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                         float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups, float eps, float momentum,
+                                         int32_t relu, void* ws, size_t ws_bytes) {
+  CSTP_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && scale_shift, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
+  CSTP_REQUIRE((size_t)(n / groups) * s > 1, "train-mode BatchNorm needs more than 1 value per channel");
+  CSTP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must come as a pair");
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_b16_bn_workspace_bytes(n, c, s, groups), "workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int npg = n / groups, ns = b16_bn_nsplit(npg, c);
+  double* part = reinterpret_cast<double*>(ws);
+  const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  const dim3 rgrid(c, groups * ns);
+  if (v8) hipLaunchKernelGGL((b16_bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+  else hipLaunchKernelGGL((b16_bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(b16_bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean, running_var,
+                     c, groups, ns, (double)npg * s, eps, momentum, gamma, beta, reinterpret_cast<float2*>(scale_shift));
+  CSTP_LAUNCH_CHECK();
+  const int chunks = cdiv(s, B16_UNROLL * 256 * (v8 ? 8 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  const float2* ss = reinterpret_cast<const float2*>(scale_shift);
+  if (v8) hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, ss, c, s, npg, relu, chunks);
+  else hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, ss, c, s, npg, relu, chunks);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, const float* scale_shift, uint16_t* dx,
+                                    uint16_t* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
+                                    int32_t relu, void* ws, size_t ws_bytes, int32_t accumulate) {
+  CSTP_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta, "null argument");
+  CSTP_REQUIRE(y != nullptr || !relu || scale_shift != nullptr, "ReLU mask needs y or scale_shift");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0 && groups > 0 && (n % groups) == 0, "bad shape");
+  CSTP_REQUIRE(ws && ws_bytes >= cstp_b16_bn_workspace_bytes(n, c, s, groups), "workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int npg = n / groups, ns = b16_bn_nsplit(npg, c);
+  double* part = reinterpret_cast<double*>(ws);
+  float* gsum = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
+  const float2* ss = reinterpret_cast<const float2*>(scale_shift);
+  const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
+                                    reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dresidual)) & 15) == 0;
+  const dim3 rgrid(c, groups * ns);
+  if (v8) hipLaunchKernelGGL((b16_bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss);
+  else hipLaunchKernelGGL((b16_bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss);
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(b16_bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0);
+  CSTP_LAUNCH_CHECK();
+  const float inv_count = (float)(1.0 / ((double)npg * s));
+  const int chunks = cdiv(s, B16_UNROLL * 256 * (v8 ? 8 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  if (v8) hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
+  else hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- pooling ------------------------------------------------------------------------------------------------------------------
+static bool b16_pool_dims(int D, int H, int W, const int32_t* k, const int32_t* st, const int32_t* pd, int& Do, int& Ho, int& Wo) {
+  for (int i = 0; i < 3; ++i)
+    if (k[i] <= 0 || st[i] <= 0 || pd[i] < 0 || 2 * pd[i] > k[i]) return false;
+  Do = (D + 2 * pd[0] - k[0]) / st[0] + 1;
+  Ho = (H + 2 * pd[1] - k[1]) / st[1] + 1;
+  Wo = (W + 2 * pd[2] - k[2]) / st[2] + 1;
+  return Do > 0 && Ho > 0 && Wo > 0;
+}
+
+extern "C" int cstp_b16_maxpool3d_forward(void* stream, const uint16_t* x, uint16_t* y, int32_t* argmax, int32_t rows, int32_t d, int32_t h,
+                                          int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3) {
+  CSTP_REQUIRE(x && y && argmax && kernel3 && stride3 && pad3 && rows > 0 && d > 0 && h > 0 && w > 0, "bad argument");
+  int Do, Ho, Wo;
+  CSTP_REQUIRE(b16_pool_dims(d, h, w, kernel3, stride3, pad3, Do, Ho, Wo), "bad pooling geometry");
+  CSTP_REQUIRE((size_t)d * h * w < (1ull << 31), "plane too large for int32 argmax");
+  const size_t total = (size_t)rows * Do * Ho * Wo;
+  hipLaunchKernelGGL(b16_maxpool3d_fwd_kernel, dim3(b16_grid(total, 256)), dim3(256), 0, as_stream(stream), x, y, argmax, rows, d, h, w, Do,
+                     Ho, Wo, kernel3[0], kernel3[1], kernel3[2], stride3[0], stride3[1], stride3[2], pad3[0], pad3[1], pad3[2]);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_maxpool3d_backward(void* stream, const uint16_t* dy, const int32_t* argmax, uint16_t* dx, int32_t rows, int32_t d,
+                                           int32_t h, int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3) {
+  CSTP_REQUIRE(dy && argmax && dx && kernel3 && stride3 && pad3 && rows > 0 && d > 0 && h > 0 && w > 0, "bad argument");
+  int Do, Ho, Wo;
+  CSTP_REQUIRE(b16_pool_dims(d, h, w, kernel3, stride3, pad3, Do, Ho, Wo), "bad pooling geometry");
+  const size_t total = (size_t)rows * d * h * w;
+  hipLaunchKernelGGL(b16_maxpool3d_bwd_kernel, dim3(b16_grid(total, 256)), dim3(256), 0, as_stream(stream), dy, argmax, dx, rows, d, h, w, Do,
+                     Ho, Wo, kernel3[0], kernel3[1], kernel3[2], stride3[0], stride3[1], stride3[2], pad3[0], pad3[1], pad3[2]);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_avgpool_forward(void* stream, const uint16_t* x, float* y, int32_t rows, int32_t s) {
+  CSTP_REQUIRE(x && y && rows > 0 && s > 0, "bad argument");
+  hipLaunchKernelGGL(b16_avgpool_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, y, rows, s);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_avgpool_backward(void* stream, const float* dy, uint16_t* dx, int32_t rows, int32_t s) {
+  CSTP_REQUIRE(dy && dx && rows > 0 && s > 0, "bad argument");
+  hipLaunchKernelGGL(b16_avgpool_bwd_kernel, dim3(b16_grid((size_t)rows * s, 256)), dim3(256), 0, as_stream(stream), dy, dx, rows, s);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}

@@ -78,6 +78,9 @@ def generate_model(opts):
         else:
             model = R3DBYOL(pretrain=False, cls_bn=True, opts=opts)
     else:
+        if getattr(opts, "act_dtype", "fp32") not in ("fp32", None):
+            raise NotImplementedError("--act_dtype %s: the bf16-storage kernels serve --model_name r3d_byol (BASELINE configs[4]); "
+                                      "r21d_byol runs fp32 storage" % (opts.act_dtype,))
         layer_sizes = layer_sizes_for_depth(opts.model_depth)
         if opts.task in PRETRAIN_TASKS:
             model = R21DBYOL(pretrain=True, layer_sizes=layer_sizes)

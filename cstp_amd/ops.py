@@ -486,7 +486,12 @@ def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None, gra
     """F.conv3d drop-in (fp32, NCDHW).  ``bn_groups`` > 0: the caller feeds the result to a train-mode ``batch_norm_act`` with
     that many groups -- the convolution then leaves the BatchNorm's statistics beside its output where its kernel can.
     ``bn_pivot`` ([C_out], e.g. that BatchNorm's running_mean): the sums are taken around it (cstp_conv3d_forward_bnstats).
-    ``grad_join``: x also feeds another op of this module that was given the same GradJoin (see there)."""
+    ``grad_join``: x also feeds another op of this module that was given the same GradJoin (see there).
+    A bfloat16 ``x`` selects the bf16-storage path (below): bf16 result, fp32 weight and weight gradient."""
+    if x.dtype == torch.bfloat16:
+        if bias is not None:
+            raise _lib.CstpError("bf16-storage conv3d is bias-free (models/BE/r3d_byol.py:45-53)")
+        return _Conv3dB16.apply(x, w, _triple(stride), _triple(padding))
     y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups), bn_pivot, grad_join)
     st = _Conv3d._last_stats
     _Conv3d._last_stats = None
@@ -600,7 +605,11 @@ class _BNAct(torch.autograd.Function):
 def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual=None, relu=False, eps=BN_EPS,
                    momentum=BN_MOMENTUM, groups=1, grad_join=None):
     """y = act(batch_norm_train(x) + residual); running stats updated in place.  ``groups`` > 1: the batch is
-    that many independent BN calls back to back (per-group statistics, sequential running-stat updates)."""
+    that many independent BN calls back to back (per-group statistics, sequential running-stat updates).
+    A bfloat16 ``x`` (and residual) selects the bf16-storage path."""
+    if x.dtype == torch.bfloat16:
+        return _BNActB16.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
+                               int(groups))
     _BNAct._pre_stats = _bnstats_of(x, int(groups))
     y = _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
                      int(groups), grad_join)
@@ -853,12 +862,206 @@ class _MaxPool3d(torch.autograd.Function):
 
 def max_pool3d(x, kernel_size=3, stride=2, padding=1):
     """nn.MaxPool3d(kernel_size, stride, padding) (models/BE/r3d_byol.py:158)."""
+    if x.dtype == torch.bfloat16:
+        return _MaxPool3dB16.apply(x, _triple(kernel_size), _triple(stride), _triple(padding))
     return _MaxPool3d.apply(x, _triple(kernel_size), _triple(stride), _triple(padding))
 
 
 def global_avg_pool(x):
-    """AdaptiveAvgPool3d(1) + view(-1, C)."""
+    """AdaptiveAvgPool3d(1) + view(-1, C).  bfloat16 in -> float32 out (the heads behind it are fp32)."""
+    if x.dtype == torch.bfloat16:
+        return _AvgPoolB16.apply(x)
     return _AvgPool.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# the bf16-STORAGE path (csrc/b16.hip; BASELINE configs[4]), selected by the dtype of the activation tensor:
+# 5-D activations and their gradients bf16, parameters / their gradients / statistics fp32 (cstp_hip.h "bf16-STORAGE path")
+# ----------------------------------------------------------------------------------------------
+def _req16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.CstpError("%s must be on a HIP device (cstp_amd has no CPU path)" % name)
+    if t.dtype != torch.bfloat16:
+        raise _lib.CstpError("%s must be bfloat16 on the bf16-storage path, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """The fp32 clip rounded to bf16 (what autocast does to the first convolution's input); no gradient flows into a clip."""
+    lib = _lib.load()
+    x = _req(x.detach(), "clip")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.cstp_b16_cast(_stream(), x.data_ptr(), y.data_ptr(), x.numel()), "cstp_b16_cast")
+    return y
+
+
+class _Conv3dB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        lib = _lib.load()
+        w_in = w
+        x = _req16(x, "conv3d input")
+        w = _req(w, "conv3d weight")
+        desc = _desc(x.shape, w.shape, stride, padding)
+        y = torch.empty(conv_out_shape(x.shape, w.shape, stride, padding), dtype=torch.bfloat16, device=x.device)
+        ws = _workspace(x.device, lib.cstp_b16_conv3d_workspace_bytes(ctypes.byref(desc)))
+        with _span("conv3d_forward", lambda: ("bf16",) + _desc_key(desc)):
+            check(lib.cstp_b16_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                              ws.numel()), "cstp_b16_conv3d_forward")
+        ctx.save_for_backward(x, w)
+        ctx.w_param = w_in
+        ctx.desc = desc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        desc = ctx.desc
+        dy = _req16(dy, "conv3d grad_output")
+        nbytes = lib.cstp_b16_conv3d_workspace_bytes(ctypes.byref(desc))
+        dx = dw = None
+        direct_w = ctx.needs_input_grad[1] and _direct(ctx.w_param)
+
+        def wgrad(dst, accumulate):
+            wsx = _workspace(x.device, nbytes)
+            with _span("conv3d_backward_weight", lambda: ("bf16",) + _desc_key(desc)):
+                check(lib.cstp_b16_conv3d_backward_weight(_stream(), ctypes.byref(desc), x.data_ptr(), dy.data_ptr(), dst.data_ptr(),
+                                                          wsx.data_ptr(), wsx.numel(), 1 if accumulate else 0),
+                      "cstp_b16_conv3d_backward_weight")
+
+        if direct_w and OVERLAP_WGRAD:      # as _Conv3d.backward: the weight gradient feeds nothing downstream in the chain
+            main = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                wgrad(ctx.w_param.grad, True)
+            x.record_stream(side)
+            dy.record_stream(side)
+            _queue_join(x.device)
+        elif direct_w:
+            wgrad(ctx.w_param.grad, True)
+        elif ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            wgrad(dw, False)
+        if ctx.needs_input_grad[0]:
+            ws = _workspace(x.device, nbytes)
+            dx = torch.empty_like(x)
+            with _span("conv3d_backward_data", lambda: ("bf16",) + _desc_key(desc)):
+                check(lib.cstp_b16_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
+                                                        ws.data_ptr(), ws.numel()), "cstp_b16_conv3d_backward_data")
+        return dx, dw, None, None
+
+
+class _BNActB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
+        lib = _lib.load()
+        ctx.param_objs = (gamma, beta)     # the parameter objects themselves (their .grad may be an arena slice)
+        x = _req16(x, "batch_norm input")
+        gamma = _req(gamma, "batch_norm weight")
+        beta = _req(beta, "batch_norm bias")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        res = None if residual is None else _req16(residual, "residual")
+        if res is not None and res.shape != x.shape:
+            raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
+        if groups < 1 or n % groups != 0:
+            raise _lib.CstpError("batch of %d rows cannot be split into %d BN groups" % (n, groups))
+        y = torch.empty_like(x)
+        mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+        ss = torch.empty(groups * c * 2, dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, lib.cstp_b16_bn_workspace_bytes(n, c, s, groups))
+        with _span("bn_forward", (n, c, s, groups, res is not None, bool(relu), "bf16")):
+            check(lib.cstp_b16_bn_forward_train(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                                                ss.data_ptr(), n, c, s, groups, eps, momentum, 1 if relu else 0, ws.data_ptr(),
+                                                ws.numel()), "cstp_b16_bn_forward_train")
+        # ReLU without a residual: backward recomputes the mask from x with the affine table instead of re-reading y
+        ctx.remask = bool(relu and res is None)
+        ctx.save_for_backward(x, ss if ctx.remask else y, gamma, mean, invstd, ss)
+        ctx.relu, ctx.groups, ctx.has_res = relu, groups, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y_or_ss, gamma, mean, invstd, ss = ctx.saved_tensors
+        y = None if ctx.remask else y_or_ss
+        dy = _req16(dy, "batch_norm grad_output")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        pg, pb = ctx.param_objs
+        direct = ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _direct(pg) and _direct(pb)
+        dgamma = pg.grad if direct else torch.empty_like(gamma)
+        dbeta = pb.grad if direct else torch.empty_like(gamma)
+        ws = _workspace(x.device, lib.cstp_b16_bn_workspace_bytes(n, c, s, ctx.groups))
+        with _span("bn_backward", (n, c, s, ctx.groups, ctx.has_res, bool(ctx.relu), "bf16")):
+            check(lib.cstp_b16_bn_backward(_stream(), x.data_ptr(), _ptr(y), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                           invstd.data_ptr(), ss.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(),
+                                           dbeta.data_ptr(), n, c, s, ctx.groups, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(),
+                                           1 if direct else 0), "cstp_b16_bn_backward")
+        if direct:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+class _MaxPool3dB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        lib = _lib.load()
+        x = _req16(x, "max_pool3d input")
+        if x.dim() != 5:
+            raise _lib.CstpError("max_pool3d expects [N, C, D, H, W], got %s" % (tuple(x.shape),))
+        n, c, d, h, w = x.shape
+        osz = tuple((sz + 2 * padding[i] - kernel[i]) // stride[i] + 1 for i, sz in enumerate((d, h, w)))
+        y = torch.empty((n, c) + osz, dtype=torch.bfloat16, device=x.device)
+        idx = torch.empty((n, c) + osz, dtype=torch.int32, device=x.device)
+        check(lib.cstp_b16_maxpool3d_forward(_stream(), x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, d, h, w,
+                                             (ctypes.c_int32 * 3)(*kernel), (ctypes.c_int32 * 3)(*stride),
+                                             (ctypes.c_int32 * 3)(*padding)), "cstp_b16_maxpool3d_forward")
+        ctx.save_for_backward(idx)
+        ctx.geom = (tuple(x.shape), tuple(kernel), tuple(stride), tuple(padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        shape, kernel, stride, padding = ctx.geom
+        dy = _req16(dy, "max_pool3d grad_output")
+        dx = torch.empty(shape, dtype=torch.bfloat16, device=dy.device)
+        n, c, d, h, w = shape
+        check(lib.cstp_b16_maxpool3d_backward(_stream(), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n * c, d, h, w,
+                                              (ctypes.c_int32 * 3)(*kernel), (ctypes.c_int32 * 3)(*stride),
+                                              (ctypes.c_int32 * 3)(*padding)), "cstp_b16_maxpool3d_backward")
+        return dx, None, None, None
+
+
+class _AvgPoolB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _req16(x, "avgpool input")
+        n, c = x.shape[0], x.shape[1]
+        s = x.numel() // (n * c)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(lib.cstp_b16_avgpool_forward(_stream(), x.data_ptr(), y.data_ptr(), n * c, s), "cstp_b16_avgpool_forward")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _req(dy, "avgpool grad_output")
+        dx = torch.empty(ctx.shape, dtype=torch.bfloat16, device=dy.device)
+        n, c = ctx.shape[0], ctx.shape[1]
+        check(lib.cstp_b16_avgpool_backward(_stream(), dy.data_ptr(), dx.data_ptr(), n * c, dx.numel() // (n * c)),
+              "cstp_b16_avgpool_backward")
+        return dx
 
 
 # ----------------------------------------------------------------------------------------------

@@ -21,6 +21,11 @@ encoder's output": ``view(-1, F)``; Predictor Linear(F, 4096) -> BN1d -> ReLU ->
 with the F-wide target feature); overlap_spa / overlap_tem Linear(2F, 5); pb_cls / rot_cls Linear(F, 4); classify_bn
 BatchNorm1d(F); classify Linear(F, n_classes).  For F = 512 this is the reference, key for key.
 
+bf16 STORAGE (configs[4] says bf16; ``opts.act_dtype == "bf16"``, pre-training only): the clip is rounded to bf16 once and every
+5-D activation / activation gradient of the encoders is bf16 in HBM, arithmetic fp32, parameters / gradients / statistics /
+pooled features / heads / losses fp32 -- the spec in include/cstp_hip.h ("bf16-STORAGE path") and csrc/b16.hip, restated by
+oracle/r3d_byol_oracle.py (storage="bf16").  cstp_amd.ops dispatches on the dtype of the activation tensor.
+
 All arithmetic runs in the HIP kernels of libcstp_hip.so through cstp_amd.ops: the 3x3x3 convolutions are the 27-tap case of the
 implicit-GEMM kernels, the stem the 343-tap / 3-channel case, MaxPool3d has its own kernel pair.
 """
@@ -178,6 +183,13 @@ class R3DBYOL(ByolBase):
     def __init__(self, momentum=0.996, pretrain=True, cls_bn=False, opts=None):
         super().__init__()
         self.pretrain = bool(pretrain)
+        act = getattr(opts, "act_dtype", "fp32") or "fp32"
+        if act not in ("fp32", "bf16"):
+            raise ValueError("--act_dtype %r: fp32 | bf16" % (act,))
+        if act == "bf16" and not pretrain:
+            raise NotImplementedError("--act_dtype bf16 covers the pre-training step (train-mode BatchNorm); fine-tune / test "
+                                      "run with fp32 activations")
+        self.act_bf16 = act == "bf16"
         kw = dict(sample_size=opts.sample_size, sample_duration=opts.sample_duration, shortcut_type=opts.sc_type,
                   num_classes=opts.n_classes)
         if pretrain:
@@ -212,6 +224,8 @@ class R3DBYOL(ByolBase):
                 raise ValueError("o_type='loss_com' needs two clips of identical shape")
             b = x1.shape[0]
             x = torch.cat((x1, x2), dim=0)     # both views through one launch sequence, per-view BN statistics (groups=2)
+            if self.act_bf16:
+                x = ops.to_bf16(x)             # bf16 storage: ops dispatch on the activation dtype from here on
             if OVERLAP_TARGET_FORWARD and x.is_cuda:
                 # target forward on a second HIP stream, staggered behind the online stem + layer1 (see R21DBYOL.forward)
                 main = torch.cuda.current_stream(x.device)

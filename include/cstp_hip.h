@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 16
+#define CSTP_ABI_VERSION 17
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -340,6 +340,50 @@ int cstp_sgd_step(void* stream, float* p, float* g, float* buf, size_t n, const 
  * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  `step` counts from 1; lr is a DEVICE scalar. */
 int cstp_adam_step(void* stream, float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, const float* lr,
                    float beta1, float beta2, float eps, float weight_decay, int32_t decoupled, int32_t step);
+
+/* ---- the bf16-STORAGE path (BASELINE configs[4]: 3D-ResNet-50 backbone swap, bf16) --------------------------------
+ * The ATen call-sites of models/BE/r3d_byol.py under bf16 activations (what torch.autocast(bfloat16) makes of them): every
+ * 5-D activation tensor and every gradient of one is bf16 in HBM (uint16_t* below = raw bf16 bits, NCDHW, contiguous), all
+ * arithmetic between a load and a store is fp32 (fp64 in the BatchNorm reductions), each stored value is rounded to
+ * nearest-even once; weights, weight gradients, BatchNorm parameters / statistics stay fp32; convolution operands are the
+ * bf16 activations and the fp32 weights rounded to bf16 at use (v_mfma_f32_16x16x32_bf16, fp32 accumulation).
+ * Geometry limits: channel counts that are multiples of 16 with at most 27 taps (every layer of the network but the stem), or
+ * any channel count with taps * channels <= 1056 (the 3-channel 7x7x7 stem, forward and weight gradient only); every
+ * gathered tensor < 2 GiB.  Anything else is refused with an error, not emulated. */
+/* x.to(torch.bfloat16) of the clip (r3d_byol.py:193-194 under autocast): n floats -> n bf16, round to nearest even. */
+int cstp_b16_cast(void* stream, const float* x, uint16_t* y, size_t n);
+size_t cstp_b16_conv3d_workspace_bytes(const cstp_conv_desc* desc);
+/* F.conv3d(x, w) of r3d_byol.py:45-53 (conv3x3x3), :104-111 (Bottleneck 1x1x1 / 3x3x3 / 1x1x1), :150-152 (7x7x7 stem),
+ * :177-180 (1x1x1 shortcut): y[n][k][do][ho][wo] bf16. */
+int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* desc, const uint16_t* x, const float* w, uint16_t* y, void* ws,
+                            size_t ws_bytes);
+/* its autograd backward w.r.t. the input: dx[n][c][d][h][w] bf16 (every element written). */
+int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const uint16_t* dy, const float* w, uint16_t* dx,
+                                  void* ws, size_t ws_bytes);
+/* ... and w.r.t. the weight: dw[k][c][kt][kh][kw] fp32, accumulate != 0: dw += (fp32 atomics: the summation order over the
+ * positions is not fixed from run to run). */
+int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const uint16_t* x, const uint16_t* dy, float* dw,
+                                    void* ws, size_t ws_bytes, int32_t accumulate);
+size_t cstp_b16_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups);
+/* relu(bn(x) + residual) in train mode (r3d_byol.py:84-95, :117-135, :153-154, :181): as cstp_bn_forward_train on bf16 x /
+ * residual / y; scale_shift (float[groups][c][2], required) receives the affine form the apply pass uses. */
+int cstp_b16_bn_forward_train(void* stream, const uint16_t* x, const uint16_t* residual, uint16_t* y, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                              float* scale_shift, int32_t n, int32_t c, int32_t s, int32_t groups, float eps, float momentum,
+                              int32_t relu, void* ws, size_t ws_bytes);
+/* its backward: as cstp_bn_backward_am (y == NULL with relu: the mask is recomputed from x and scale_shift). */
+int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint16_t* y, const uint16_t* dy, const float* gamma,
+                         const float* save_mean, const float* save_invstd, const float* scale_shift, uint16_t* dx,
+                         uint16_t* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
+                         int32_t relu, void* ws, size_t ws_bytes, int32_t accumulate);
+/* nn.MaxPool3d r3d_byol.py:158 on bf16 (same tie rule and argmax as cstp_maxpool3d_forward). */
+int cstp_b16_maxpool3d_forward(void* stream, const uint16_t* x, uint16_t* y, int32_t* argmax, int32_t rows, int32_t d, int32_t h,
+                               int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3);
+int cstp_b16_maxpool3d_backward(void* stream, const uint16_t* dy, const int32_t* argmax, uint16_t* dx, int32_t rows, int32_t d,
+                                int32_t h, int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3);
+/* nn.AdaptiveAvgPool3d(1) r3d_byol.py:203: bf16 rows -> fp32 means; backward: fp32 dy -> bf16 dx. */
+int cstp_b16_avgpool_forward(void* stream, const uint16_t* x, float* y, int32_t rows, int32_t s);
+int cstp_b16_avgpool_backward(void* stream, const float* dy, uint16_t* dx, int32_t rows, int32_t s);
 
 #ifdef __cplusplus
 }

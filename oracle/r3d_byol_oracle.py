@@ -15,6 +15,14 @@ What each function follows (paths relative to /root/reference/models/BE/r3d_byol
 * ``ft_forward``                      :420-428 ('ft_fc' / 'ft_all' / 'test'), :429-432 ('scratch')
 * ``bottleneck_block``                Bottleneck.forward :117-137 (1x1x1 -> 3x3x3 stride s -> 1x1x1 x4, BN after each)
 
+bf16 STORAGE (``set_storage("bf16")``; BASELINE configs[4] says bf16, the reference has no reduced-precision mode: PARITY-UNPINNED
+spec of include/cstp_hip.h "bf16-STORAGE path"): the same functions with the product path's rounding points restated -- every
+5-D activation is rounded to bf16 where its producer writes it (convolution outputs; BatchNorm (+residual) (+ReLU) outputs, once,
+after the activation), every gradient of such a tensor where the consumer's backward writes it and again where autograd sums
+two of them; convolution weights are rounded to bf16 at use, their gradients are not; statistics, pooled features, heads,
+losses and the optimiser are untouched.  The arithmetic between the rounding points runs in the dtype of the state (fp64 in
+the tests), so what is left between this oracle and the HIP path is fp32 accumulation order and the rounding flips it causes.
+
 Depth 50 (BASELINE configs[4]): the reference's BACKBONE modules (conv1 .. layer4, avgpool) are sound and pin this file's
 ``encoder_forward`` through ``tests/golden/r3d_50_backbone.npz``; its WRAPPER is not -- ``view(-1, 512)`` of the 2048 pooled
 features (:204) quadruples the batch, and Predictor / heads are hard-wired to 512 inputs (:212,226,249-252) -- so for depth 50
@@ -34,6 +42,71 @@ from . import r21d_byol_oracle as base
 LAYERS = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3)}
 EXPANSION = {10: 1, 18: 1, 34: 1, 50: 4}
 _exp = {"v": 1}          # expansion of the spec / forward being built (set by for_depth)
+
+
+_storage = {"kind": None}
+
+
+def set_storage(kind) -> None:
+    """None / "fp32": no rounding (the reference's arithmetic).  "bf16": the bf16-storage spec (module docstring)."""
+    if kind not in (None, "fp32", "bf16"):
+        raise ValueError(kind)
+    _storage["kind"] = None if kind in (None, "fp32") else kind
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundBoth(torch.autograd.Function):
+    """A tensor edge at its producer: the value is rounded where it is written; the (summed) gradient arriving from the
+    consumers is rounded too (autograd adds bf16 gradient tensors in bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """A tensor edge at one consumer: the gradient that consumer's backward writes is rounded."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+class _RoundValue(torch.autograd.Function):
+    """Weights: rounded at use, the gradient flows to the fp32 master weight unrounded."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return _bf(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _out(x):
+    return _RoundBoth.apply(x) if _storage["kind"] == "bf16" else x
+
+
+def _in(x):
+    return _RoundGrad.apply(x) if (_storage["kind"] == "bf16" and x.requires_grad) else x
+
+
+def _conv(x, w, stride, padding):
+    if _storage["kind"] == "bf16":
+        return _out(F.conv3d(_in(x), _RoundValue.apply(w), None, stride, padding))
+    return F.conv3d(x, w, None, stride, padding)
 
 
 def for_depth(depth: int):
@@ -125,40 +198,42 @@ def closed_form_labels(b: int):
 
 
 def basic_block(sd, prefix, x, stride, training=True):
-    out = F.conv3d(x, sd[prefix + ".conv1.weight"], None, stride, 1)
-    out = F.relu(base._bn(sd, prefix + ".bn1", out, training))
-    out = F.conv3d(out, sd[prefix + ".conv2.weight"], None, 1, 1)
-    out = base._bn(sd, prefix + ".bn2", out, training)
+    out = _conv(x, sd[prefix + ".conv1.weight"], stride, 1)
+    out = _out(F.relu(base._bn(sd, prefix + ".bn1", _in(out), training)))
+    out = _conv(out, sd[prefix + ".conv2.weight"], 1, 1)
+    out = base._bn(sd, prefix + ".bn2", _in(out), training)
     residual = x
     if (prefix + ".downsample.0.weight") in sd:
-        residual = F.conv3d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
-        residual = base._bn(sd, prefix + ".downsample.1", residual, training)
-    return F.relu(out + residual)
+        residual = _conv(x, sd[prefix + ".downsample.0.weight"], stride, 0)
+        residual = _out(base._bn(sd, prefix + ".downsample.1", _in(residual), training))
+    return _out(F.relu(out + _in(residual)))       # BN + residual + ReLU is ONE kernel: rounded once, behind the activation
 
 
 def bottleneck_block(sd, prefix, x, stride, training=True):
-    out = F.conv3d(x, sd[prefix + ".conv1.weight"], None, 1, 0)
-    out = F.relu(base._bn(sd, prefix + ".bn1", out, training))
-    out = F.conv3d(out, sd[prefix + ".conv2.weight"], None, stride, 1)
-    out = F.relu(base._bn(sd, prefix + ".bn2", out, training))
-    out = F.conv3d(out, sd[prefix + ".conv3.weight"], None, 1, 0)
-    out = base._bn(sd, prefix + ".bn3", out, training)
+    out = _conv(x, sd[prefix + ".conv1.weight"], 1, 0)
+    out = _out(F.relu(base._bn(sd, prefix + ".bn1", _in(out), training)))
+    out = _conv(out, sd[prefix + ".conv2.weight"], stride, 1)
+    out = _out(F.relu(base._bn(sd, prefix + ".bn2", _in(out), training)))
+    out = _conv(out, sd[prefix + ".conv3.weight"], 1, 0)
+    out = base._bn(sd, prefix + ".bn3", _in(out), training)
     residual = x
     if (prefix + ".downsample.0.weight") in sd:
-        residual = F.conv3d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
-        residual = base._bn(sd, prefix + ".downsample.1", residual, training)
-    return F.relu(out + residual)
+        residual = _conv(x, sd[prefix + ".downsample.0.weight"], stride, 0)
+        residual = _out(base._bn(sd, prefix + ".downsample.1", _in(residual), training))
+    return _out(F.relu(out + _in(residual)))
 
 
 def encoder_forward(sd, prefix, x, layers, training=True):
-    x = F.conv3d(x, sd[prefix + ".conv1.weight"], None, (1, 2, 2), (3, 3, 3))
-    x = F.relu(base._bn(sd, prefix + ".bn1", x, training))
-    x = F.max_pool3d(x, 3, 2, 1)
+    if _storage["kind"] == "bf16":
+        x = _bf(x)                                  # the clip is rounded once
+    x = _conv(x, sd[prefix + ".conv1.weight"], (1, 2, 2), (3, 3, 3))
+    x = _out(F.relu(base._bn(sd, prefix + ".bn1", _in(x), training)))
+    x = _out(F.max_pool3d(_in(x), 3, 2, 1))
     for li, n in enumerate(layers):
         for bi in range(n):
             blk = bottleneck_block if (prefix + ".layer1.0.conv3.weight") in sd else basic_block
             x = blk(sd, "%s.layer%d.%d" % (prefix, li + 1, bi), x, 2 if (bi == 0 and li > 0) else 1, training)
-    return x.mean(dim=(2, 3, 4)).flatten(1)        # view(-1, 512) for the BasicBlock depths; view(-1, 2048) at depth 50 (spec)
+    return _in(x).mean(dim=(2, 3, 4)).flatten(1)   # view(-1, 512) for the BasicBlock depths; view(-1, 2048) at depth 50 (spec)
 
 
 def ema_update(sd, layers, m: float = base.EMA_MOMENTUM):

@@ -1,0 +1,308 @@
+"""The bf16-STORAGE path (csrc/b16.hip, BASELINE configs[4]) on a real MI355X, through the C ABI (cstp_amd.ops dispatches on
+the activation dtype).
+
+Tolerance, stated before the tests were written.  A bf16 value has 8 significand bits: ONE rounding is <= 2^-9 = 1.95e-3
+relative.  The spec (include/cstp_hip.h) rounds every stored activation once from an fp32 result, so
+  * an op-level OUTPUT stored in bf16 must equal bf16(the fp64 result on the same bf16 operands) except where the fp32
+    accumulation error (~1e-6 relative) carries the value across a rounding boundary: every element within ONE bf16 ulp of
+    the exact result, and at most 1 element in 1000 different from its correctly rounded value;
+  * fp32 outputs (weight gradients, BatchNorm statistics and parameter gradients, pooled means) are fp32-accurate on the bf16
+    operands: 2e-5 of the tensor's largest magnitude (fp32 atomics over up to 1e5 positions);
+  * model level, against the oracle of the same spec (oracle/r3d_byol_oracle.py, storage="bf16", fp64 between the rounding
+    points): the two differ by rounding flips only -- losses 1e-2, logits 2e-2 of their largest magnitude, global gradient
+    norm 5e-2.
+Restated after the first GPU run (gpurun_out/b1, b2; tools/b16_grad_err.py), for depth 50 only: a flipped bf16 rounding is a
+4e-3 perturbation of one element, and 53 train-mode BatchNorm layers over a handful of values per channel amplify it -- the
+ORACLE ITSELF, run with fp32 instead of fp64 between the same rounding points, lands 2e-2 .. 3e-2 (logits) and 1e-2 .. 2e-2
+(gradient norm) from its fp64 run at 4 clips of 8x64x64, with per-tensor gradient VECTORS 0.9 apart in norm (the direction is
+not determined at bf16 resolution in that configuration).  The depth-50 case therefore runs 8 clips of 8x96x96 (oracle fp32
+vs fp64: logits 2e-2, gradient norm 1.4e-3) with the logits bar at 5e-2; the other bars stand, and the test prints the
+oracle's own fp32 distance next to the HIP path's.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cstp_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda", 0)
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def ulp_bf16(ref):
+    """Spacing of bf16 numbers at |ref| (fp64 tensor)."""
+    e = torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -126)))
+    return torch.pow(torch.tensor(2.0, dtype=torch.float64), e - 7)
+
+
+def check_rounded(got_bf16, exact64, what):
+    got = got_bf16.detach().cpu().double()
+    want = exact64.to(torch.bfloat16).double()
+    err = (got - exact64).abs()
+    # within one bf16 ulp of the exact value everywhere (tiny absolute floor: sums that cancel to ~0)
+    floor = 1e-5 * float(exact64.abs().max())
+    bad = err > ulp_bf16(exact64) + floor
+    assert not bool(bad.any()), "%s: %d elements further than one bf16 ulp, worst %g at value %g" % (
+        what, int(bad.sum()), float(err.max()), float(exact64.flatten()[int(err.argmax())]))
+    flips = float((got != want).double().mean())
+    assert flips < 1e-3, "%s: %.2e of the elements differ from the correctly rounded value" % (what, flips)
+
+
+CONVS = [
+    # (n, c, d, h, w), k, kernel, stride, padding
+    ((2, 64, 4, 14, 14), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # Bottleneck conv3
+    ((2, 256, 4, 14, 14), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # Bottleneck conv1
+    ((2, 64, 4, 14, 14), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # Bottleneck conv2 / BasicBlock
+    ((2, 32, 4, 14, 14), 48, (3, 3, 3), (2, 2, 2), (1, 1, 1)),        # strided 3x3x3, 48 rows (ragged row tile)
+    ((3, 64, 3, 9, 7), 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),         # shortcut, odd extents
+    ((2, 16, 3, 10, 10), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # one 16-channel group per tap: odd group count
+    ((2, 3, 8, 32, 32), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),         # the stem: offset-table mode
+    ((4, 128, 1, 1, 1), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # one position per sample (layer4 of a small clip)
+    ((2, 48, 2, 5, 5), 80, (1, 3, 3), (1, 1, 1), (0, 1, 1)),          # 5x5 frames: nothing is a multiple of 4 or 8
+]
+
+
+@pytest.mark.parametrize("xs,k,kern,stride,pad", CONVS)
+def test_conv3d_bf16_forward_backward(xs, k, kern, stride, pad):
+    g = torch.Generator().manual_seed(sum(xs) + k)
+    x = bf(torch.randn(xs, generator=g))
+    w = torch.randn((k, xs[1]) + kern, generator=g) / np.sqrt(xs[1] * np.prod(kern))
+    x64 = x.double().requires_grad_(True)
+    w64 = bf(w).double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, stride, pad)
+    dy = bf(torch.randn(y64.shape, generator=g))
+    dx64, dw64 = torch.autograd.grad(y64, (x64, w64), dy.double())
+
+    xd = x.to(DEV).requires_grad_(xs[1] % 16 == 0)
+    wd = w.to(DEV).requires_grad_(True)
+    y = ops.conv3d(xd, wd, None, stride, pad)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == tuple(y64.shape)
+    check_rounded(y, y64.detach(), "forward")
+    y.backward(dy.to(DEV))
+    assert wd.grad.dtype == torch.float32
+    err = float((wd.grad.cpu().double() - dw64).abs().max() / dw64.abs().max())
+    assert err < 2e-5, "weight gradient %g" % err
+    if xd.requires_grad:
+        assert xd.grad.dtype == torch.bfloat16
+        check_rounded(xd.grad, dx64, "data gradient")
+
+
+def test_conv3d_bf16_weight_gradient_accumulates_into_an_existing_gradient():
+    g = torch.Generator().manual_seed(5)
+    x = bf(torch.randn((2, 32, 2, 6, 6), generator=g)).to(DEV).requires_grad_(True)
+    w = (torch.randn((32, 32, 1, 1, 1), generator=g) / 6).to(DEV).requires_grad_(True)
+    dy = bf(torch.randn((2, 32, 2, 6, 6), generator=g)).to(DEV)
+    ops.conv3d(x, w, None, 1, 0).backward(dy)
+    g1 = w.grad.clone()
+    x.grad = None
+    ops.conv3d(x, w, None, 1, 0).backward(dy)          # autograd accumulates: twice the gradient
+    assert float((w.grad - 2 * g1).abs().max() / g1.abs().max()) < 1e-5
+
+
+def test_conv3d_bf16_refuses_what_it_does_not_serve():
+    from cstp_amd import _lib
+    x = torch.zeros((1, 24, 2, 4, 4), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.CstpError):        # 24 channels x 5x5x5 = 3000 > the offset table
+        ops.conv3d(x, torch.zeros((16, 24, 5, 5, 5), device=DEV), None, 1, 2)
+    with pytest.raises(_lib.CstpError):
+        ops.conv3d(x, torch.zeros((16, 24, 1, 1, 1), device=DEV), torch.zeros(16, device=DEV), 1, 0)
+    with pytest.raises(_lib.CstpError):        # fp32 weights only
+        ops.conv3d(x, torch.zeros((16, 24, 1, 1, 1), dtype=torch.bfloat16, device=DEV), None, 1, 0)
+
+
+def _bn_ref(x, gamma, beta, res, relu, groups, eps=1e-5):
+    n = x.shape[0]
+    outs = []
+    for gi in range(groups):
+        sl = slice(gi * n // groups, (gi + 1) * n // groups)
+        xx = x[sl]
+        mu = xx.mean(dim=(0, 2, 3, 4), keepdim=True)
+        var = xx.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+        y = (xx - mu) / torch.sqrt(var + eps) * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)
+        if res is not None:
+            y = y + res[sl]
+        outs.append(F.relu(y) if relu else y)
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("shape,groups,res,relu", [((4, 64, 4, 14, 14), 2, False, True), ((4, 64, 4, 14, 14), 2, True, True),
+                                                   ((4, 32, 2, 5, 5), 1, True, False), ((6, 24, 3, 7, 7), 2, False, True),
+                                                   ((8, 128, 1, 1, 1), 2, True, True), ((2, 16, 8, 56, 56), 1, False, True)])
+def test_batch_norm_bf16_forward_backward(shape, groups, res, relu):
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[1]
+    x = bf(torch.randn(shape, generator=g) * 1.5 + 0.3)
+    r = bf(torch.randn(shape, generator=g)) if res else None
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.2
+    dy = bf(torch.randn(shape, generator=g))
+    x64 = x.double().requires_grad_(True)
+    r64 = None if r is None else r.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = _bn_ref(x64, g64, b64, r64, relu, groups)
+    grads = torch.autograd.grad(y64, [x64, g64, b64] + ([r64] if res else []), dy.double())
+
+    xd = x.to(DEV).requires_grad_(True)
+    rd = None if r is None else r.to(DEV).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    y = ops.batch_norm_act(xd, gd, bd, rm, rv, rd, relu, groups=groups)
+    assert y.dtype == torch.bfloat16
+    # the apply pass computes fma(x, scale, shift) with fp32 (scale, shift): a handful more flips than a convolution's sum
+    got, want = y.detach().cpu().double(), y64.detach()
+    assert float((got - want).abs().max()) <= float((ulp_bf16(want) + 2e-6 * want.abs().max()).max())
+    assert bool(((got - want).abs() <= ulp_bf16(want) + 1e-5 * float(want.abs().max())).all())
+    y.backward(dy.to(DEV))
+    assert xd.grad.dtype == torch.bfloat16
+    assert bool(((xd.grad.cpu().double() - grads[0]).abs() <= ulp_bf16(grads[0]) + 2e-5 * float(grads[0].abs().max())).all())
+    assert float((gd.grad.cpu().double() - grads[1]).abs().max() / grads[1].abs().max()) < 2e-5
+    assert float((bd.grad.cpu().double() - grads[2]).abs().max() / grads[2].abs().max()) < 2e-5
+    if res:
+        check_rounded(rd.grad, grads[3], "residual gradient")
+    # running statistics: group after group, unbiased variance, momentum 0.1
+    erm, erv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    n = shape[0]
+    for gi in range(groups):
+        xx = x.double()[gi * n // groups:(gi + 1) * n // groups]
+        erm = 0.9 * erm + 0.1 * xx.mean(dim=(0, 2, 3, 4))
+        erv = 0.9 * erv + 0.1 * xx.var(dim=(0, 2, 3, 4), unbiased=True)
+    assert float((rm.cpu().double() - erm).abs().max()) < 1e-6 and float((rv.cpu().double() - erv).abs().max() / erv.abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 9, 11), (2, 64, 4, 16, 16), (1, 3, 7, 7, 7)])
+def test_pooling_bf16(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = bf(torch.randn(shape, generator=g))
+    x[0, 0, :2, :3, :3] = 0.5          # ties: the first maximum in scan order wins
+    x64 = x.double().requires_grad_(True)
+    y64 = F.max_pool3d(x64, 3, 2, 1)
+    dy = bf(torch.randn(y64.shape, generator=g))
+    (dx64,) = torch.autograd.grad(y64, x64, dy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.max_pool3d(xd, 3, 2, 1)
+    assert y.dtype == torch.bfloat16 and torch.equal(y.detach().cpu().double(), y64.detach())
+    y.backward(dy.to(DEV))
+    check_rounded(xd.grad, dx64, "max-pool gradient")         # up to 8 bf16 gradients summed in fp32, rounded once
+    xd.grad = None
+    m = ops.global_avg_pool(xd)
+    assert m.dtype == torch.float32
+    assert float((m.detach().cpu().double() - x.double().mean(dim=(2, 3, 4))).abs().max()) < 1e-5
+    dm = torch.randn(m.shape, generator=g)
+    m.backward(dm.to(DEV))
+    s = shape[2] * shape[3] * shape[4]
+    want = (dm.double() / s).view(shape[0], shape[1], 1, 1, 1).expand(shape)
+    check_rounded(xd.grad, want.contiguous(), "avg-pool gradient")
+
+
+def test_cast_bf16_is_round_to_nearest_even():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(100003, generator=g) * torch.pow(10.0, torch.randint(-6, 6, (100003,), generator=g).float())
+    x[:4] = torch.tensor([1.00390625, 1.01171875, -1.00390625, 0.0])        # ties: to even
+    y = ops.to_bf16(x.to(DEV))
+    assert y.dtype == torch.bfloat16 and torch.equal(y.cpu(), x.to(torch.bfloat16))
+
+
+def _opts(depth, t, hw, act="bf16", k=101):
+    return argparse.Namespace(model_depth=depth, sample_size=hw, sample_duration=t, sc_type="B", n_classes=k, act_dtype=act)
+
+
+@pytest.mark.parametrize("depth,b,t,hw", [(18, 4, 8, 64), (50, 8, 8, 96)])
+def test_r3d_bf16_step_matches_the_bf16_storage_oracle(depth, b, t, hw):
+    """One optimisation step of the product's PretrainStep with --act_dtype bf16 against the CPU oracle of the same spec
+    (storage="bf16", fp64 between the rounding points), and the distance of both from the unrounded fp64 run."""
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r3d_byol import R3DBYOL
+    from cstp_amd.train import PretrainStep
+    from oracle import r21d_byol_oracle as orc
+    from oracle import r3d_byol_oracle as r3d
+    layers = r3d.for_depth(depth)
+    try:
+        sd = r3d.closed_form_state(r3d.model_spec(layers), torch.float32)
+        y1, y2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
+        labels = r3d.closed_form_labels(b)
+        w = (0.1, 1.0, 1.0, 1.0, 1.0)
+        r3d.set_storage("bf16")
+        osd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        info = r3d.train_step(osd, {}, y1.double(), y2.double(), labels, layers, 0.05, 0.9, 5e-4, w, True)
+        # the same spec with fp32 between the rounding points: what ANY fp32 implementation of it can be expected to reach
+        i32 = r3d.train_step({k: v.clone() for k, v in sd.items()}, {}, y1, y2, labels, layers, 0.05, 0.9, 5e-4, w, True)
+        r3d.set_storage(None)
+        model = R3DBYOL(pretrain=True, opts=_opts(depth, t, hw))
+        res = model.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        model.cuda()
+        arenas = model.flatten_parameters()
+        model.train()
+        opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=arenas)
+        step = PretrainStep(model, opt, w, clip_grad_norm=True)
+        lab = {k: v.cuda() for k, v in labels.items()}
+        out = step(y1.cuda(), y2.cuda(), lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+
+        def rel(a, bb):
+            a, bb = np.asarray(a, dtype=np.float64), np.asarray(bb, dtype=np.float64)
+            return float(np.abs(a - bb).max() / max(np.abs(bb).max(), 1e-30))
+
+        e = {"loss_byol": rel(float(out.loss_byol), float(info["loss_byol"])),
+             "loss_total": rel(float(out.loss_total), float(info["loss_total"])),
+             "logits": rel(torch.stack([l.cpu() for l in out.logits[:2]]).numpy(), torch.stack(info["logits"][:2]).numpy()),
+             "grad_norm": rel(float(out.grad_norm), float(info["grad_norm"]))}
+        e32 = {"loss_total": rel(float(i32["loss_total"]), float(info["loss_total"])),
+               "logits": rel(torch.stack(i32["logits"][:2]).numpy(), torch.stack(info["logits"][:2]).numpy()),
+               "grad_norm": rel(float(i32["grad_norm"]), float(info["grad_norm"]))}
+        print("bf16 depth %d: HIP vs bf16 oracle (fp64 between roundings) %s; the oracle's own fp32 run vs the same %s" % (depth, e, e32))
+        logits_bar = 5e-2 if depth >= 50 else 2e-2
+        assert e["loss_byol"] < 1e-2 and e["loss_total"] < 1e-2 and e["logits"] < logits_bar and e["grad_norm"] < 5e-2, (e, e32)
+        assert np.isfinite(float(out.loss_total)) and bool(torch.isfinite(arenas["param"]).all())
+    finally:
+        r3d.set_storage(None)
+        r3d.for_depth(18)
+
+
+def test_full_size_properties_r3d50_cfg5_share_bf16():
+    """BASELINE configs[4] as it is written -- 3D-ResNet-50, 3x16x224x224, bf16 -- at its per-GPU share (4 clip pairs of the
+    global 32 over 8 GPUs): one optimisation step with bf16 activation storage, through properties that need no oracle run."""
+    from conftest import rel_err
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r3d_byol import R3DBYOL
+    from cstp_amd.synthetic import device_batch
+    from cstp_amd.train import PretrainStep
+    torch.manual_seed(1)
+    model = R3DBYOL(pretrain=True, opts=_opts(50, 16, 224)).cuda()
+    a = model.flatten_parameters()
+    model.train()
+    lr, wd = 0.01, 5e-4
+    opt = FlatSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=wd, arenas=a)
+    step = PretrainStep(model, opt, (0.1, 1.0, 1.0, 1.0, 1.0), clip_grad_norm=True)
+    x1, x2, lab = device_batch(4, 16, 224, DEV, seed=1)
+    t_before, q_before, p_before = a["target"].clone(), a["param"][:a["n_encoder"]].clone(), a["param"].clone()
+    out = step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+    torch.cuda.synchronize()
+    assert [tuple(l.shape) for l in out.logits] == [(4, 5), (4, 5), (4, 4), (4, 4), (4, 4), (4, 4)]
+    assert np.isfinite(float(out.loss_total)) and 0.0 <= float(out.loss_byol) <= 8.0
+    assert bool(torch.isfinite(a["grad"]).all()) and bool(torch.isfinite(a["param"]).all())
+    assert rel_err(a["target"], t_before * 0.996 + q_before * (1.0 - 0.996)) < 1e-6
+    gnorm = float(out.grad_norm)
+    coef = min(1.0, 18.0 / (gnorm + 1e-6))
+    assert abs(float(a["grad"].double().norm()) - gnorm * coef) / (gnorm * coef) < 1e-4
+    assert rel_err(a["param"], p_before - lr * (a["grad"] + wd * p_before)) < 1e-5
+    msd = model.state_dict()
+    assert int(msd["online_net.bn1.num_batches_tracked"]) == 2 and int(msd["target_net.bn1.num_batches_tracked"]) == 2
+    # the same step with fp32 storage: the bf16 run must stay close to it (loss within 5 %)
+    torch.manual_seed(1)
+    m32 = R3DBYOL(pretrain=True, opts=_opts(50, 16, 224, act="fp32")).cuda()
+    a32 = m32.flatten_parameters()
+    m32.train()
+    s32 = PretrainStep(m32, FlatSGD(m32.parameters(), lr=lr, momentum=0.9, weight_decay=wd, arenas=a32), (0.1, 1.0, 1.0, 1.0, 1.0),
+                       clip_grad_norm=True)
+    o32 = s32(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+    print("cfg5 share: loss bf16 %.5f fp32 %.5f, grad norm bf16 %.4f fp32 %.4f" % (float(out.loss_total), float(o32.loss_total),
+                                                                               gnorm, float(o32.grad_norm)))
+    assert abs(float(out.loss_total) - float(o32.loss_total)) / abs(float(o32.loss_total)) < 5e-2

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Pre-training throughput of the 3D-ResNet-BYOL wrapper on one MI355X (synthetic clips resident in HBM): the per-GPU share of
 BASELINE.json configs[4] (B = 32 over 8 GPUs -> 4 clip pairs per GPU, 3x16x224x224) on the BasicBlock depths the reference can
-can run (10 / 18 / 34) and on the Bottleneck depth 50 that configs[4] names (corrected wrapper: cstp_amd/r3d_byol.py), fp32 storage.
+can run (10 / 18 / 34) and on the Bottleneck depth 50 that configs[4] names (corrected wrapper: cstp_amd/r3d_byol.py), with fp32 or
+bf16 activation storage (--act_dtype; configs[4] says bf16).
 
-    python tools/bench_r3d.py --depth 18 --batch 4 --size 224 --steps 10
+    python tools/bench_r3d.py --depth 50 --batch 4 --size 224 --steps 10 --act_dtype bf16
 
 Not the headline metric (bench.py is) -- a sizing aid for the backbone swap."""
 import argparse
@@ -30,10 +31,11 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--act_dtype", default="fp32", choices=("fp32", "bf16"))
     a = ap.parse_args()
     torch.manual_seed(1)
     dev = torch.device("cuda", 0)
-    opts = argparse.Namespace(model_depth=a.depth, sample_size=a.size, sample_duration=a.frames, sc_type="B", n_classes=400)
+    opts = argparse.Namespace(model_depth=a.depth, sample_size=a.size, sample_duration=a.frames, sc_type="B", n_classes=400, act_dtype=a.act_dtype)
     model = R3DBYOL(pretrain=True, opts=opts).cuda()
     arenas = model.flatten_parameters()
     model.train()
@@ -50,8 +52,8 @@ def main():
     run(a.steps)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
-    print(json.dumps({"config": {"workload": "r3d_byol 3D-ResNet-%d, B=%d clip pairs 3x%dx%dx%d, full loss_com, clip 18, SGD; fp32"
-                                 % (a.depth, a.batch, a.frames, a.size, a.size)},
+    print(json.dumps({"config": {"workload": "r3d_byol 3D-ResNet-%d, B=%d clip pairs 3x%dx%dx%d, full loss_com, clip 18, SGD; %s activation storage"
+                                 % (a.depth, a.batch, a.frames, a.size, a.size, a.act_dtype)},
                       "ms_per_step": round(ms, 2), "clips_per_s": round(a.batch / ms * 1e3, 2),
                       "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
