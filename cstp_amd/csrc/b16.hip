@@ -17,7 +17,10 @@
 //                              swizzled LDS double buffer, one barrier per K-tile.  TAB: reduction index k = tap * C + c over a
 //                              zero-padded copy with a per-k offset table (the 3-channel 7x7x7 stem).
 //   wgrad_b16_kernel<TAB>      dW[m][k] += sum_p dY[m][p] * Xcol[k][p]: 64 x 64 tile, reduction over 64-position chunks,
-//                              split over the positions, fp32 atomics into the gradient.
+//                              split over the positions; every split leaves an fp32 slab, b16_wgrad_reduce_kernel sums them in a
+//                              fixed order into dw[m][c][tap] (deterministic; no atomics).
+//   split-K                    layers with few positions (14x14 / 7x7 frames) split the K loop of conv_b16_kernel over blockIdx.y
+//                              into fp32 slabs summed by b16_sum_slabs_kernel: 16 blocks x 432 K-tiles become 512 x 14.
 //   BatchNorm / pooling / cast: HBM-streaming, 16-byte (8 x bf16) accesses where rows allow.
 #include "common.h"
 
@@ -115,6 +118,7 @@ struct B16Conv {
   int Kw;                          // elements per packed weight row
   int contig;                      // four consecutive q are four consecutive, 8-byte aligned outputs of one sample
   int n_tiles_x, n_tiles_m;
+  int ksplit;                      // > 1: blockIdx.y owns a slice of the K-tiles and leaves an fp32 partial tile in its slab
   int kh, kw;                      // TAB: kernel extent (for the offset table)
   short off[B16_MAXTAPS][4];       // per list entry: source offset (t, h, w), weight tap index
 };
@@ -125,7 +129,8 @@ __device__ __forceinline__ int b16_slot(int row, int c) { return row * 4 + (c ^ 
 
 template <int MT, bool TAB>
 __global__ void __launch_bounds__(256)
-conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __restrict__ wp, u16* __restrict__ out) {
+conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __restrict__ wp, u16* __restrict__ out,
+                float* __restrict__ slab, size_t slab_stride) {
   constexpr int BM = 16 * MT;
   constexpr int NW = BM / 64;                       // 16-byte weight chunks per thread and K-tile
   __shared__ uint4 Xs[2][128 * 4];
@@ -177,8 +182,14 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const __amdgpu_buffer_rsrc_t rs_src = b16_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 2));
   const int gpt = TAB ? 1 : (g.Cs >> 4);                                // 16-channel groups per tap
   const int ngroups = TAB ? (g.Kw >> 4) : g.ntaps * gpt;
-  const int ntiles = (ngroups + 1) >> 1;
-  int ti = g2 / gpt, cg = g2 - ti * gpt;                                // (tap entry, channel group) of my group in K-tile 0
+  const int ntiles_all = (ngroups + 1) >> 1;
+  // split-K: layers with few positions (a 7x7 frame: 4 position tiles) would leave most of the chip idle and every block
+  // latency-bound on a long K loop -- blockIdx.y takes K-tiles [kt_lo, kt_hi) and the partial tiles are summed by
+  // b16_sum_slabs_kernel (deterministic: no atomics)
+  const int tps = (ntiles_all + g.ksplit - 1) / g.ksplit;
+  const int kt_lo = blockIdx.y * tps;
+  const int kt_hi = (kt_lo + tps) < ntiles_all ? (kt_lo + tps) : ntiles_all;
+  int ti = (2 * kt_lo + g2) / gpt, cg = (2 * kt_lo + g2) - ti * gpt;    // (tap entry, channel group) of my group in my first K-tile
   const unsigned tab_base = (unsigned)(((size_t)nb * g.Cs * g.Ds + cd0) * HWs + ch0 * g.Ws + cw0) * 2u;   // TAB: bytes
 
   // ---- my part of the weight tile: row wrow (+64), chunk wc of the K-tile (group wc >> 1, half wc & 1)
@@ -255,14 +266,14 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
+  issue(kt_lo);
   advance();
   stage(0);
   __syncthreads();
   const int frow = lane & 15, fchunk = lane >> 4;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < ntiles;
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
+    const int buf = (kt - kt_lo) & 1;
+    const bool more = kt + 1 < kt_hi;
     if (more) { issue(kt + 1); advance(); }
     bf16x8 xa[2];
 #pragma unroll
@@ -283,6 +294,7 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
 
   // ---- epilogue: lane holds positions 4 * (lane >> 4) + r (r = 0..3) of position tile a, channel (lane & 15) of row tile b
   const int DHWo = g.Do * g.Ho * g.Wo, HWo = g.Ho * g.Wo;
+  float* sl = g.ksplit > 1 ? slab + (size_t)blockIdx.y * slab_stride : nullptr;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int P0 = n0 + wave * 32 + a * 16 + 4 * (lane >> 4);
@@ -294,7 +306,9 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
         const int m = m0 + b * 16 + (lane & 15);
         if (m >= g.M) continue;
         const f32x4 v = acc[a][b];
-        *reinterpret_cast<uint2*>(out + ((size_t)nbo * g.M + m) * DHWo + pos) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        const size_t o = ((size_t)nbo * g.M + m) * DHWo + pos;
+        if (sl != nullptr) *reinterpret_cast<f32x4*>(sl + o) = v;
+        else *reinterpret_cast<uint2*>(out + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
       }
     } else {
       size_t ooff[4];
@@ -315,10 +329,30 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
         if (m >= g.M) continue;
         const f32x4 v = acc[a][b];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ok[r]) out[ooff[r] + (size_t)m * DHWo] = f2bf(v[r]);
+        for (int r = 0; r < 4; ++r) {
+          if (!ok[r]) continue;
+          if (sl != nullptr) sl[ooff[r] + (size_t)m * DHWo] = v[r];
+          else out[ooff[r] + (size_t)m * DHWo] = f2bf(v[r]);
+        }
       }
     }
+  }
+}
+
+// out[i] = bf16(sum over the S slabs of slab[s][i]) (fixed order: bit-reproducible)
+__global__ void __launch_bounds__(256)
+b16_sum_slabs_kernel(const float* __restrict__ slab, int S, size_t stride, u16* __restrict__ out, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(slab + 4 * i);
+    for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(slab + (size_t)s * stride + 4 * i);
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    float a = slab[i];
+    for (int s = 1; s < S; ++s) a += slab[(size_t)s * stride + i];
+    out[i] = f2bf(a);
   }
 }
 
@@ -331,6 +365,7 @@ struct B16Wgrad {
   int vec8;                        // Do*Ho*Wo % 8 == 0: eight consecutive positions of a dY row are one aligned 16-byte load
   int nchunks, chunks_per_split;   // 64-position chunks
   int kh, kw;
+  int Kp;                          // slab row length (K rounded up to 64)
   short off[B16_MAXTAPS][4];
 };
 
@@ -338,7 +373,7 @@ constexpr int WG_ROW = 9;          // uint4 per LDS row: 64 positions x 2 B + 16
 
 template <bool TAB>
 __global__ void __launch_bounds__(256)
-wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ dw) {
+wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ slab) {
   __shared__ uint4 Ys[2][64 * WG_ROW];
   __shared__ uint4 Xs[2][64 * WG_ROW];
   __shared__ int taps[B16_MAXTAPS * 4];
@@ -346,8 +381,7 @@ wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restr
   const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
   const int c_lo = blockIdx.z * g.chunks_per_split;
   int c_hi = c_lo + g.chunks_per_split;
-  c_hi = c_hi < g.nchunks ? c_hi : g.nchunks;
-  if (c_lo >= c_hi) return;
+  c_hi = c_hi < g.nchunks ? c_hi : g.nchunks;      // (the host sizes the grid so that every split owns at least one chunk)
   if (!TAB && t < g.ntaps * 4) taps[t] = g.off[t >> 2][t & 3];
   __syncthreads();
   const int npo = g.Do * g.Ho * g.Wo, npos = g.Nb * npo;
@@ -466,34 +500,37 @@ wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restr
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds rows m = 4 * (lane >> 4) + r of row tile a, column (lane & 15) of column tile b
-  const int ntaps_w = TAB ? g.ntaps : g.kh;       // grouped mode: kh carries the layer's total tap count
+  // ---- epilogue: lane holds rows m = 4 * (lane >> 4) + r of row tile a, column (lane & 15) of column tile b: the partial tile
+  //      goes to this split's slab [M rounded to 64][Kp] in GEMM layout (64-byte runs; the first version added straight into
+  //      dw[m][c][tap] with fp32 atomics: 64 cache lines per instruction at the memory side -- most of the kernel's time)
+  float* sl = slab + (size_t)blockIdx.z * ((size_t)gridDim.y * 64 * g.Kp);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const int col = (nt0 + b) * 16 + (lane & 15);
-    int c, wtap;
-    bool cok;
-    if (TAB) {
-      const int k = k0 + col;
-      cok = k < g.K;
-      wtap = k / g.Cs;
-      c = k - wtap * g.Cs;
-    } else {
-      const int gj = (k0 >> 4) + (col >> 4);
-      cok = gj < g.ntaps * gpt;
-      const int tj = cok ? gj / gpt : 0;
-      c = (gj - tj * gpt) * 16 + (col & 15);
-      wtap = taps[tj * 4 + 3];
-    }
-    if (!cok) continue;
+    const int col = k0 + (nt0 + b) * 16 + (lane & 15);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (mt0 + a) * 16 + 4 * (lane >> 4) + r;
-        if (m < g.M) atomicAdd(dw + ((size_t)m * g.Cs + c) * ntaps_w + wtap, acc[a][b][r]);
+        sl[(size_t)m * g.Kp + col] = acc[a][b][r];
       }
     }
+  }
+}
+
+// dw[m][c][tap] (+)= sum over the S slabs of slab[s][m][k = tap * C + c]   (fixed order: bit-reproducible)
+__global__ void __launch_bounds__(256)
+b16_wgrad_reduce_kernel(const float* __restrict__ slab, int S, size_t stride, float* __restrict__ dw, int M, int Cs, int ntaps, int K,
+                        int Kp, int accumulate) {
+  const size_t total = (size_t)M * K;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % K), m = (int)(i / K);
+    const float* p = slab + (size_t)m * Kp + k;
+    float a = p[0];
+    for (int s = 1; s < S; ++s) a += p[(size_t)s * stride];
+    const int tap = k / Cs, c = k - tap * Cs;
+    float* d = dw + ((size_t)m * Cs + c) * ntaps + tap;
+    *d = accumulate ? *d + a : a;
   }
 }
 
@@ -801,12 +838,61 @@ static size_t b16_pad_bytes(const cstp_conv_desc* d, const B16Geom& q) {
   return q.tab ? align_up((size_t)d->n * d->c * q.Dp * q.Hp * q.Wp * 2, 256) : 0;
 }
 
+// split-K factor of a forward / data-gradient launch sequence: a function of the geometry alone (so that the workspace
+// query and the launches agree).  blocks0 = blocks without splitting, ntiles = K-tiles of the longest tap list.
+constexpr size_t B16_SLAB_CAP = (size_t)128 << 20;
+static int b16_conv_split(int blocks0, int ntiles, size_t out_elems) {
+  if (blocks0 >= 768 || ntiles < 8) return 1;
+  int S = 768 / blocks0;
+  if (S > ntiles / 4) S = ntiles / 4;
+  const size_t cap = B16_SLAB_CAP / (out_elems * sizeof(float));
+  if ((size_t)S > cap) S = (int)cap;
+  return S < 2 ? 1 : S;
+}
+static int b16_fwd_split(const cstp_conv_desc* d, const B16Geom& q) {
+  const int BM = d->k > 64 ? 128 : 64;
+  const int blocks0 = cdiv(d->n * q.Do * q.Ho * q.Wo, 128) * cdiv(d->k, BM);
+  const int ngroups = q.tab ? q.Kw / 16 : q.ntaps * (d->c / 16);
+  return b16_conv_split(blocks0, (ngroups + 1) / 2, (size_t)d->n * d->k * q.Do * q.Ho * q.Wo);
+}
+static int b16_dgrad_split(const cstp_conv_desc* d, const B16Geom& q) {
+  if ((d->k % 16) != 0) return 1;
+  const int BM = d->c > 64 ? 128 : 64;
+  // the launches of the stride-parity classes run back to back: together they have about the blocks of one un-strided launch
+  const int blocks0 = cdiv(d->n * d->d * d->h * d->w, 128) * cdiv(d->c, BM);
+  const int taps_class = cdiv(d->kt, d->st) * cdiv(d->kh, d->sh) * cdiv(d->kw, d->sw);
+  return b16_conv_split(blocks0, (taps_class * (d->k / 16) + 1) / 2, (size_t)d->n * d->c * d->d * d->h * d->w);
+}
+// weight gradient: positions split over S blocks per tile, each leaving an fp32 slab [M rounded to 64][K rounded to 64]
+static int b16_wgrad_split(const cstp_conv_desc* d, const B16Geom& q) {
+  const int K = q.ntaps * d->c;
+  const int tiles = cdiv(K, 64) * cdiv(d->k, 64);
+  const int nchunks = cdiv(d->n * q.Do * q.Ho * q.Wo, 64);
+  int S = cdiv(1536, tiles);
+  if (S > nchunks) S = nchunks;
+  const size_t slab = (size_t)cdiv(d->k, 64) * 64 * cdiv(K, 64) * 64 * sizeof(float);
+  const size_t cap = B16_SLAB_CAP / slab;
+  if ((size_t)S > cap) S = (int)cap;
+  if (S < 1) S = 1;
+  const int cps = cdiv(nchunks, S);
+  return cdiv(nchunks, cps);                 // every split owns at least one chunk
+}
+
+static size_t b16_wpack_bytes(const cstp_conv_desc* d, const B16Geom& q) {
+  const size_t mp_f = align_up((size_t)d->k, 128), mp_d = align_up((size_t)d->c, 128);
+  const size_t wf = align_up(mp_f * q.Kw * 2, 256), wd = align_up(mp_d * (size_t)q.ntaps * d->k * 2, 256);
+  return wf > wd ? wf : wd;
+}
+
 extern "C" size_t cstp_b16_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
   B16Geom q;
   if (!b16_geom(desc, q)) return 0;
-  const size_t mp_f = align_up((size_t)desc->k, 128), mp_d = align_up((size_t)desc->c, 128);
-  const size_t wf = align_up(mp_f * q.Kw * 2, 256), wd = align_up(mp_d * (size_t)q.ntaps * desc->k * 2, 256);
-  return (wf > wd ? wf : wd) + b16_pad_bytes(desc, q) + 256;
+  const int sf = b16_fwd_split(desc, q), sd = b16_dgrad_split(desc, q), sw = b16_wgrad_split(desc, q);
+  size_t slabs = 0;
+  if (sf > 1) slabs = (size_t)sf * desc->n * desc->k * q.Do * q.Ho * q.Wo * sizeof(float);
+  if (sd > 1) { const size_t b = (size_t)sd * desc->n * desc->c * desc->d * desc->h * desc->w * sizeof(float); slabs = b > slabs ? b : slabs; }
+  { const size_t b = (size_t)sw * cdiv(desc->k, 64) * 64 * cdiv(q.ntaps * desc->c, 64) * 64 * sizeof(float); slabs = b > slabs ? b : slabs; }
+  return b16_wpack_bytes(desc, q) + b16_pad_bytes(desc, q) + align_up(slabs, 256) + 256;
 }
 
 extern "C" int cstp_b16_cast(void* stream, const float* x, uint16_t* y, size_t n) {
@@ -818,13 +904,18 @@ extern "C" int cstp_b16_cast(void* stream, const float* x, uint16_t* y, size_t n
 }
 
 template <bool TAB>
-static void b16_launch_conv(hipStream_t st, const B16Conv& g, int M, const uint16_t* src, const void* wp, uint16_t* out) {
+static void b16_launch_conv(hipStream_t st, const B16Conv& g, int M, const uint16_t* src, const void* wp, uint16_t* out, float* slab,
+                            size_t slab_stride) {
   const int chunk = (g.n_tiles_x + 7) / 8;
-  const unsigned blocks = (unsigned)(8 * chunk * g.n_tiles_m);
+  const dim3 grid((unsigned)(8 * chunk * g.n_tiles_m), (unsigned)g.ksplit);
   if (M > 64)
-    hipLaunchKernelGGL((conv_b16_kernel<8, TAB>), dim3(blocks), dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out);
+    hipLaunchKernelGGL((conv_b16_kernel<8, TAB>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
   else
-    hipLaunchKernelGGL((conv_b16_kernel<4, TAB>), dim3(blocks), dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out);
+    hipLaunchKernelGGL((conv_b16_kernel<4, TAB>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
+}
+
+static float* b16_slabs(void* ws, const cstp_conv_desc* d, const B16Geom& q) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + b16_wpack_bytes(d, q) + b16_pad_bytes(d, q));
 }
 
 extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, const uint16_t* x, const float* w, uint16_t* y, void* ws,
@@ -855,13 +946,16 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
   g.n_tiles_m = Mp / BM;
   g.kh = d->kh; g.kw = d->kw;
   g.ntaps = q.ntaps;
+  g.ksplit = b16_fwd_split(d, q);
+  float* slab = b16_slabs(ws, d, q);
+  const size_t out_elems = (size_t)d->n * d->k * q.Do * q.Ho * q.Wo;
   if (q.tab) {
-    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + align_up((size_t)align_up((size_t)d->k, 128) * q.Kw * 2, 256));
+    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + b16_wpack_bytes(d, q));
     hipLaunchKernelGGL(pad_b16_kernel, dim3(b16_grid((size_t)d->n * d->c * q.Dp * q.Hp, 4)), dim3(256), 0, st, x, xp, d->n * d->c, d->d,
                        d->h, d->w, d->pt, d->ph, d->pw);
     CSTP_LAUNCH_CHECK();
     g.Ds = q.Dp; g.Hs = q.Hp; g.Ws = q.Wp;
-    b16_launch_conv<true>(st, g, d->k, xp, wp, y);
+    b16_launch_conv<true>(st, g, d->k, xp, wp, y, slab, out_elems);
   } else {
     g.Ds = d->d; g.Hs = d->h; g.Ws = d->w;
     int i = 0;
@@ -870,9 +964,13 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
         for (int c = 0; c < d->kw; ++c, ++i) {
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
-    b16_launch_conv<false>(st, g, d->k, x, wp, y);
+    b16_launch_conv<false>(st, g, d->k, x, wp, y, slab, out_elems);
   }
   CSTP_LAUNCH_CHECK();
+  if (g.ksplit > 1) {
+    hipLaunchKernelGGL(b16_sum_slabs_kernel, dim3(b16_grid(out_elems / 4 + 1, 256)), dim3(256), 0, st, slab, g.ksplit, out_elems, y, out_elems);
+    CSTP_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -891,6 +989,9 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
   u16* wp = reinterpret_cast<u16*>(ws);
   hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, Kw, 1);
   CSTP_LAUNCH_CHECK();
+  const int ksplit = b16_dgrad_split(d, q);
+  float* slab = b16_slabs(ws, d, q);
+  const size_t out_elems = (size_t)d->n * d->c * d->d * d->h * d->w;
   for (int zt = 0; zt < d->st; ++zt)
     for (int zh = 0; zh < d->sh; ++zh)
       for (int zw = 0; zw < d->sw; ++zw) {
@@ -917,9 +1018,14 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
               ++i;
             }
         g.ntaps = i;
-        b16_launch_conv<false>(st, g, d->c, dy, wp, dx);
+        g.ksplit = ksplit;
+        b16_launch_conv<false>(st, g, d->c, dy, wp, dx, slab, out_elems);
         CSTP_LAUNCH_CHECK();
       }
+  if (ksplit > 1) {
+    hipLaunchKernelGGL(b16_sum_slabs_kernel, dim3(b16_grid(out_elems / 4 + 1, 256)), dim3(256), 0, st, slab, ksplit, out_elems, dx, out_elems);
+    CSTP_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -931,44 +1037,42 @@ extern "C" int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_des
   CSTP_REQUIRE(q.tab || q.ntaps <= B16_MAXTAPS, "bf16 path: at most 27 filter taps for channel counts that are multiples of 16");
   CSTP_REQUIRE((size_t)d->n * d->c * q.Dp * q.Hp * q.Wp * 2 < (1ull << 31), "bf16 path: gathered tensor must be < 2 GiB");
   hipStream_t st = as_stream(stream);
-  if (!accumulate) {
-    if (hipMemsetAsync(dw, 0, (size_t)d->k * d->c * q.ntaps * sizeof(float), st) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
-  }
   B16Wgrad g;
   memset(&g, 0, sizeof(g));
   g.Nb = d->n; g.Cs = d->c;
   g.M = d->k; g.Do = q.Do; g.Ho = q.Ho; g.Wo = q.Wo;
   g.st = d->st; g.sh = d->sh; g.sw = d->sw;
   g.ntaps = q.ntaps; g.K = q.ntaps * d->c;
+  g.Kp = cdiv(g.K, 64) * 64;
   const int npo = q.Do * q.Ho * q.Wo;
   g.vec8 = ((npo % 8) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) ? 1 : 0;
   g.nchunks = cdiv(d->n * npo, 64);
-  const int tiles = cdiv(g.K, 64) * cdiv(d->k, 64);
-  int S = cdiv(2048, tiles);
-  if (S > g.nchunks) S = g.nchunks;
-  if (S < 1) S = 1;
+  const int S = b16_wgrad_split(d, q);
   g.chunks_per_split = cdiv(g.nchunks, S);
-  S = cdiv(g.nchunks, g.chunks_per_split);
   const dim3 grid(cdiv(g.K, 64), cdiv(d->k, 64), S);
+  float* slab = b16_slabs(ws, d, q);
+  const size_t slab_stride = (size_t)grid.y * 64 * g.Kp;
   if (q.tab) {
-    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + align_up((size_t)align_up((size_t)d->k, 128) * q.Kw * 2, 256));
+    u16* xp = reinterpret_cast<u16*>(reinterpret_cast<char*>(ws) + b16_wpack_bytes(d, q));
     hipLaunchKernelGGL(pad_b16_kernel, dim3(b16_grid((size_t)d->n * d->c * q.Dp * q.Hp, 4)), dim3(256), 0, st, x, xp, d->n * d->c, d->d,
                        d->h, d->w, d->pt, d->ph, d->pw);
     CSTP_LAUNCH_CHECK();
     g.Ds = q.Dp; g.Hs = q.Hp; g.Ws = q.Wp;
     g.kh = d->kh; g.kw = d->kw;
-    hipLaunchKernelGGL((wgrad_b16_kernel<true>), grid, dim3(256), 0, st, g, xp, dy, dw);
+    hipLaunchKernelGGL((wgrad_b16_kernel<true>), grid, dim3(256), 0, st, g, xp, dy, slab);
   } else {
     g.Ds = d->d; g.Hs = d->h; g.Ws = d->w;
-    g.kh = q.ntaps;                  // grouped mode: the layer's total tap count (the weight layout's innermost extent)
     int i = 0;
     for (int a = 0; a < d->kt; ++a)
       for (int b = 0; b < d->kh; ++b)
         for (int c = 0; c < d->kw; ++c, ++i) {
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
-    hipLaunchKernelGGL((wgrad_b16_kernel<false>), grid, dim3(256), 0, st, g, x, dy, dw);
+    hipLaunchKernelGGL((wgrad_b16_kernel<false>), grid, dim3(256), 0, st, g, x, dy, slab);
   }
+  CSTP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(b16_wgrad_reduce_kernel, dim3(b16_grid((size_t)d->k * g.K, 256)), dim3(256), 0, st, slab, S, slab_stride, dw, d->k,
+                     d->c, q.ntaps, g.K, g.Kp, accumulate ? 1 : 0);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

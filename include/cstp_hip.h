@@ -360,8 +360,8 @@ int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* desc, const uint
 /* its autograd backward w.r.t. the input: dx[n][c][d][h][w] bf16 (every element written). */
 int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const uint16_t* dy, const float* w, uint16_t* dx,
                                   void* ws, size_t ws_bytes);
-/* ... and w.r.t. the weight: dw[k][c][kt][kh][kw] fp32, accumulate != 0: dw += (fp32 atomics: the summation order over the
- * positions is not fixed from run to run). */
+/* ... and w.r.t. the weight: dw[k][c][kt][kh][kw] fp32, accumulate != 0: dw += (position splits through fp32 slabs summed in
+ * a fixed order: bit-reproducible). */
 int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const uint16_t* x, const uint16_t* dy, float* dw,
                                     void* ws, size_t ws_bytes, int32_t accumulate);
 size_t cstp_b16_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups);
