@@ -134,3 +134,55 @@ def test_r3d_50_backbone_oracle_matches_reference_modules(fixture):
         assert [k for k, _, _ in r3d.ft_spec(layers, 11)] == list(ft.state_dict().keys())
     finally:
         r3d.for_depth(18)
+
+
+def test_bf16_storage_spec_of_the_oracle_and_the_act_dtype_switch():
+    """The bf16-storage restatement (oracle set_storage("bf16"), parity-unpinned spec of include/cstp_hip.h): features are means of
+    bf16-representable activations, the mode leaves the unrounded path untouched, stays within bf16's distance of it, and rounds the
+    gradients of activations but not of weights; the product refuses --act_dtype bf16 where it has no kernels for it."""
+    import argparse
+    from cstp_amd.opts import parse_opts
+    from cstp_amd.r3d_byol import R3DBYOL
+    from oracle import r21d_byol_oracle as orc
+    from oracle import r3d_byol_oracle as r3d
+    layers = r3d.for_depth(10)
+    sd = r3d.closed_form_state(r3d.model_spec(layers), torch.float64)
+    y1, y2, _ = orc.closed_form_clips(2, 4, 32, torch.float64)
+    labels = r3d.closed_form_labels(2)
+    w = (0.1, 1.0, 1.0, 1.0, 1.0)
+
+    def step(kind):
+        r3d.set_storage(kind)
+        try:
+            return r3d.train_step({k: v.clone() for k, v in sd.items()}, {}, y1, y2, labels, layers, 0.05, 0.9, 5e-4, w, True)
+        finally:
+            r3d.set_storage(None)
+
+    a, b, a2 = step(None), step("bf16"), step("fp32")
+    assert float(a["loss_total"]) == float(a2["loss_total"])                       # "fp32" = no rounding
+    assert 0 < abs(float(b["loss_total"]) - float(a["loss_total"])) / abs(float(a["loss_total"])) < 2e-2
+    # (per-tensor gradient VECTORS are not comparable at this size: tools/b16_grad_err.py; the global norm is)
+    assert abs(float(b["grad_norm"]) - float(a["grad_norm"])) / float(a["grad_norm"]) < 0.1
+    g16 = b["grads"]["online_net.layer1.0.conv1.weight"]
+    assert not torch.equal(g16, g16.to(torch.bfloat16).double())                   # weight gradients are NOT rounded
+    # an activation edge: value rounded forward, gradient rounded backward
+    x = (torch.arange(64, dtype=torch.float64) / 7.0 + 0.001).requires_grad_(True)
+    r3d.set_storage("bf16")
+    try:
+        y = r3d._out(x * 1.0)
+        (y * (torch.arange(64, dtype=torch.float64) / 3.0 + 0.01)).sum().backward()
+    finally:
+        r3d.set_storage(None)
+    assert torch.equal(y.detach(), y.detach().to(torch.bfloat16).double()) and torch.equal(x.grad, x.grad.to(torch.bfloat16).double())
+    with pytest.raises(ValueError):
+        r3d.set_storage("fp16")
+    # the product's switch
+    assert parse_opts([]).act_dtype == "fp32" and parse_opts(["--act_dtype", "bf16"]).act_dtype == "bf16"
+    ns = argparse.Namespace(model_depth=10, sample_size=32, sample_duration=4, sc_type="B", n_classes=11, act_dtype="bf16")
+    assert R3DBYOL(pretrain=True, opts=ns).act_bf16 is True
+    with pytest.raises(NotImplementedError):
+        R3DBYOL(pretrain=False, cls_bn=True, opts=ns)
+    ns.act_dtype = "fp8"
+    with pytest.raises(ValueError):
+        R3DBYOL(pretrain=True, opts=ns)
+    r3d.for_depth(18)
