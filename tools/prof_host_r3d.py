@@ -1,0 +1,22 @@
+import argparse, cProfile, pstats, sys, os, time, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from cstp_amd.optim import FlatSGD
+from cstp_amd.r3d_byol import R3DBYOL
+from cstp_amd.synthetic import device_batch
+from cstp_amd.train import PretrainStep
+torch.manual_seed(1)
+dev = torch.device("cuda", 0)
+opts = argparse.Namespace(model_depth=50, sample_size=224, sample_duration=16, sc_type="B", n_classes=400, act_dtype=sys.argv[1])
+model = R3DBYOL(pretrain=True, opts=opts).cuda()
+arenas = model.flatten_parameters(); model.train()
+opt = FlatSGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4, arenas=arenas)
+step = PretrainStep(model, opt, (0.1, 1.0, 1.0, 1.0, 1.0), clip_grad_norm=True)
+x1, x2, lab = device_batch(4, 16, 224, dev, seed=1)
+def run(n):
+    for _ in range(n):
+        step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+run(3); torch.cuda.synchronize()
+t0 = time.perf_counter(); run(5); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("host enqueue per step %.2f ms; with drain %.2f ms" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
+pr = cProfile.Profile(); pr.enable(); run(5); pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
