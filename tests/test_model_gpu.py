@@ -7,7 +7,11 @@ import numpy as np
 import pytest
 import torch
 
-from test_oracle_golden import GRAD_SCALE, OUT_SCALE, STATE_SCALE, STATE_TOLS, TOLS, cs_err, is_heavy, load, rel
+from test_oracle_golden import GRAD_SCALE, OUT_SCALE, STATE_SCALE, STATE_TOLS, TOLS, cs_err, is_heavy, load, rel, run_oracle
+
+# widened fixtures: the HIP path's error against the fp64 truth may be at most this many times stock PyTorch fp32's (measured:
+# 1.2 - 2.7 depending on the tile the autotuner picked, profiles/r03/state_err_r34cfg4*.log; a broken kernel is off by 10x and more)
+HIP_VS_FP32 = 3.0
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +124,18 @@ def test_hip_path_matches_reference_golden(name):
         mcs = momentum_checksums(opt)
         assert mcs.shape == g[pre + "mom_cs"].shape
         assert cs_err(mcs, g[pre + "mom_cs"]) < gtol
+        if s == 1 and (name in GRAD_SCALE or name in STATE_SCALE):
+            # the fixtures whose bars are widened (R(2+1)D-34: noise amplification through 66 train-mode BN layers): the HIP
+            # path must stay within a fixed factor of what STOCK PyTorch fp32 -- the oracle, run here on the host -- leaves
+            # against the same fp64 truth, so that an arithmetic regression cannot hide behind the widened bar (round-2 ADVICE)
+            _, oinfos, ostates, omoms, _ = run_oracle(name, steps=1)
+            ogn = np.array([float(oinfos[0]["grads"][k].norm()) if k in oinfos[0]["grads"] else -1.0 for k in pkeys])
+            pairs = {"grad_norms": (rel(gn, g[pre + "grad_norms"]), rel(ogn, g[pre + "grad_norms"]), TOLS[1][1]),
+                     "state_cs": (cs_err(checksums(model, keys), g[pre + "state_cs"]), cs_err(ostates[0], g[pre + "state_cs"]), STATE_TOLS[1]),
+                     "mom_cs": (cs_err(mcs, g[pre + "mom_cs"]), cs_err(omoms[0], g[pre + "mom_cs"]), TOLS[1][1])}
+            print("%s: (HIP error, stock-fp32 error, unwidened bar) %s" % (name, pairs))
+            for what, (e_hip, e_fp32, base) in pairs.items():
+                assert e_hip < base or e_hip < HIP_VS_FP32 * e_fp32, (name, what, e_hip, e_fp32)
     # BN counters: online/target nets see two forwards per step (r21d_byol.py:359-366)
     msd = model.state_dict()
     assert int(msd["online_net.bn1.num_batches_tracked"]) == 2 * nsteps
