@@ -127,13 +127,22 @@ struct B16Conv {
 // the 16 rows x one chunk of a fragment read then cover all 64 banks once.
 __device__ __forceinline__ int b16_slot(int row, int c) { return row * 4 + (c ^ ((row >> 2) & 3)); }
 
-template <int MT, bool TAB>
+// PW ("pointwise": the 1x1x1 stride-1 layers -- two thirds of a Bottleneck network's convolutions -- with frames that are multiples
+// of 8 positions): no halo and no taps, so a thread gathers EIGHT consecutive positions of one channel with one 16-byte load
+// (two per thread and K-tile instead of sixteen 2-byte loads: the generic loop is bound by the number of gather instructions),
+// the LDS image is k-major (32 channel rows of 128 positions, 288-byte row stride) and the position fragments come out of it
+// k-contiguous through the transposing ds_read_b64_tr_b16 (lane 4q + p of a 16-lane group supplies row q / positions
+// 4p .. 4p + 3, lane i receives position i of the four rows).
+constexpr int PW_ROW = 18;                           // uint4 per k-row of the PW image: 16 octets of positions + 32 bytes of padding
+
+template <int MT, bool TAB, bool PW = false>
 __global__ void __launch_bounds__(256)
 conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __restrict__ wp, u16* __restrict__ out,
                 float* __restrict__ slab, size_t slab_stride) {
+  static_assert(!(TAB && PW), "the pointwise mode has no offset table");
   constexpr int BM = 16 * MT;
   constexpr int NW = BM / 64;                       // 16-byte weight chunks per thread and K-tile
-  __shared__ uint4 Xs[2][128 * 4];
+  __shared__ uint4 Xs[2][PW ? 32 * PW_ROW : 128 * 4];
   __shared__ uint4 Ws[2][BM * 4];
   __shared__ int taps[B16_MAXTAPS * 4];
   __shared__ unsigned ktab[TAB ? B16_KTAB : 4];
@@ -152,7 +161,8 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const int n0 = ntile * 128, m0 = mtile * BM;
   const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
 
-  if (!TAB) {
+  if (PW) {
+  } else if (!TAB) {
     if (t < g.ntaps * 4) taps[t] = g.off[t >> 2][t & 3];
   } else {
     const int khw = g.kh * g.kw, kreal = g.ntaps * g.Cs;
@@ -180,8 +190,8 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const unsigned nb_off = (unsigned)((size_t)nb * g.Cs * DHWs);          // elements
   const unsigned cstride = (unsigned)DHWs * 2u;                         // bytes between channels
   const __amdgpu_buffer_rsrc_t rs_src = b16_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 2));
-  const int gpt = TAB ? 1 : (g.Cs >> 4);                                // 16-channel groups per tap
-  const int ngroups = TAB ? (g.Kw >> 4) : g.ntaps * gpt;
+  const int gpt = (TAB || PW) ? 1 : (g.Cs >> 4);                        // 16-channel groups per tap
+  const int ngroups = (TAB || PW) ? (g.Kw >> 4) : g.ntaps * gpt;
   const int ntiles_all = (ngroups + 1) >> 1;
   // split-K: layers with few positions (a 7x7 frame: 4 position tiles) would leave most of the chip idle and every block
   // latency-bound on a long K loop -- blockIdx.y takes K-tiles [kt_lo, kt_hi) and the partial tiles are summed by
@@ -198,12 +208,34 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const size_t wrow64 = (size_t)64 * g.Kw * 2;
 
   u16 xr[16];
+  u32x4v xq[PW ? 2 : 1];
   uint4 wr[NW];
+  // PW: my channel row of the K-tile and my two octets of positions (lanes 0..7 of a row: 128 contiguous bytes)
+  const int krow = t >> 3;
+  unsigned pw_off[2] = {B16_OOB, B16_OOB};
+  if (PW) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int Po = n0 + 8 * ((t & 7) + 8 * e);
+      if (Po < npos) {
+        const int nbo = Po / npq, pos = Po - nbo * npq;
+        pw_off[e] = (unsigned)(((size_t)nbo * g.Cs * npq + pos) * 2);
+      }
+    }
+  }
 
   auto issue = [&](int kt) __attribute__((always_inline)) {
     // X
     unsigned vo = B16_OOB;
-    if (TAB) {
+    if (PW) {
+      const int c = kt * 32 + krow;
+      const unsigned coff = (unsigned)c * cstride;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned v = (c < g.Cs && pw_off[e] != B16_OOB) ? pw_off[e] + coff : B16_OOB;
+        xq[e] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_src, v, 0, 0));
+      }
+    } else if (TAB) {
       const int k0 = (kt * 2 + g2) * 16;
       if (pvalid && k0 < g.Kw) {
 #pragma unroll
@@ -227,7 +259,7 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
     // W
     int kel;                                                            // element offset of my chunk inside the packed row
     bool wok;
-    if (TAB) {
+    if (TAB || PW) {
       kel = kt * 32 + wc * 8;
       wok = kel < g.Kw;
     } else {
@@ -243,19 +275,25 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
-    if (!TAB) {
+    if (!TAB && !PW) {
       cg += 2;
       while (cg >= gpt) { cg -= gpt; ++ti; }
     }
   };
   auto stage = [&](int buf) __attribute__((always_inline)) {
-    uint4 a, b;
-    a.x = xr[0] | ((unsigned)xr[1] << 16); a.y = xr[2] | ((unsigned)xr[3] << 16);
-    a.z = xr[4] | ((unsigned)xr[5] << 16); a.w = xr[6] | ((unsigned)xr[7] << 16);
-    b.x = xr[8] | ((unsigned)xr[9] << 16); b.y = xr[10] | ((unsigned)xr[11] << 16);
-    b.z = xr[12] | ((unsigned)xr[13] << 16); b.w = xr[14] | ((unsigned)xr[15] << 16);
-    Xs[buf][b16_slot(p, g2 * 2)] = a;
-    Xs[buf][b16_slot(p, g2 * 2 + 1)] = b;
+    if constexpr (PW) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        Xs[buf][krow * PW_ROW + (t & 7) + 8 * e] = make_uint4(xq[e][0], xq[e][1], xq[e][2], xq[e][3]);
+    } else {
+      uint4 a, b;
+      a.x = xr[0] | ((unsigned)xr[1] << 16); a.y = xr[2] | ((unsigned)xr[3] << 16);
+      a.z = xr[4] | ((unsigned)xr[5] << 16); a.w = xr[6] | ((unsigned)xr[7] << 16);
+      b.x = xr[8] | ((unsigned)xr[9] << 16); b.y = xr[10] | ((unsigned)xr[11] << 16);
+      b.z = xr[12] | ((unsigned)xr[13] << 16); b.w = xr[14] | ((unsigned)xr[15] << 16);
+      Xs[buf][b16_slot(p, g2 * 2)] = a;
+      Xs[buf][b16_slot(p, g2 * 2 + 1)] = b;
+    }
 #pragma unroll
     for (int j = 0; j < NW; ++j) Ws[buf][b16_slot(wrow + 64 * j, wc)] = wr[j];
   };
@@ -278,8 +316,20 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
     bf16x8 xa[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const int row = wave * 32 + a * 16 + frow;
-      xa[a] = __builtin_bit_cast(bf16x8, Xs[buf][b16_slot(row, fchunk)]);
+      if constexpr (PW) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int lq = frow >> 2, lp = frow & 3, ct = wave * 2 + a;
+        const uint2* img = reinterpret_cast<const uint2*>(&Xs[buf][0]);
+        const int r_lo = 8 * fchunk + lq;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + r_lo * (2 * PW_ROW) + ct * 4 + lp));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (r_lo + 4) * (2 * PW_ROW) + ct * 4 + lp));
+        xa[a] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      } else {
+        const int row = wave * 32 + a * 16 + frow;
+        xa[a] = __builtin_bit_cast(bf16x8, Xs[buf][b16_slot(row, fchunk)]);
+      }
     }
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
@@ -371,9 +421,12 @@ struct B16Wgrad {
 
 constexpr int WG_ROW = 9;          // uint4 per LDS row: 64 positions x 2 B + 16 B padding (fragment reads conflict-free)
 
-template <bool TAB>
+// PW (the 1x1x1 stride-1 layers, frames a multiple of 8 positions): column k is channel k and its positions are contiguous -- the X
+// rows are fetched like the dY rows, two 16-byte loads per thread and chunk instead of sixteen 2-byte gathers.
+template <bool TAB, bool PW = false>
 __global__ void __launch_bounds__(256)
 wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ slab) {
+  static_assert(!(TAB && PW), "the pointwise mode has no offset table");
   __shared__ uint4 Ys[2][64 * WG_ROW];
   __shared__ uint4 Xs[2][64 * WG_ROW];
   __shared__ int taps[B16_MAXTAPS * 4];
@@ -414,10 +467,22 @@ wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restr
   const bool mvalid = m0 + yrow < g.M;
 
   u16 xr[16];
-  uint4 yr[2];
+  uint4 yr[2], xq[2];
+  const bool cvalid = k0 + yrow < g.K;                 // PW: my column (= channel) exists
   auto issue = [&](int ci) __attribute__((always_inline)) {
     const int P0 = ci * 64;
-    {
+    if constexpr (PW) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const int Pq = P0 + (yo + o) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cvalid && Pq < npos) {
+          const int nb = Pq / npo, pos = Pq - nb * npo;
+          v = *reinterpret_cast<const uint4*>(x + ((size_t)nb * g.Cs + k0 + yrow) * npo + pos);
+        }
+        xq[o] = v;
+      }
+    } else {
       int n = P0 + p;
       const bool pv = n < npos && gvalid;
       n = pv ? n : 0;
@@ -462,9 +527,14 @@ wgrad_b16_kernel(const B16Wgrad g, const u16* __restrict__ x, const u16* __restr
     }
   };
   auto stage = [&](int buf) __attribute__((always_inline)) {
-    u16* xs = reinterpret_cast<u16*>(&Xs[buf][0]);
+    if constexpr (PW) {
+      Xs[buf][yrow * WG_ROW + yo] = xq[0];
+      Xs[buf][yrow * WG_ROW + yo + 1] = xq[1];
+    } else {
+      u16* xs = reinterpret_cast<u16*>(&Xs[buf][0]);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xs[(kq * 16 + j) * (WG_ROW * 8) + p] = xr[j];
+      for (int j = 0; j < 16; ++j) xs[(kq * 16 + j) * (WG_ROW * 8) + p] = xr[j];
+    }
     Ys[buf][yrow * WG_ROW + yo] = yr[0];
     Ys[buf][yrow * WG_ROW + yo + 1] = yr[1];
   };
@@ -932,15 +1002,22 @@ extern "C" int cstp_b16_cast(void* stream, const float* x, uint16_t* y, size_t n
   return 0;
 }
 
-template <bool TAB>
+template <bool TAB, bool PW = false>
 static void b16_launch_conv(hipStream_t st, const B16Conv& g, int M, const uint16_t* src, const void* wp, uint16_t* out, float* slab,
                             size_t slab_stride) {
   const int chunk = (g.n_tiles_x + 7) / 8;
   const dim3 grid((unsigned)(8 * chunk * g.n_tiles_m), (unsigned)g.ksplit);
   if (M > 64)
-    hipLaunchKernelGGL((conv_b16_kernel<8, TAB>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
+    hipLaunchKernelGGL((conv_b16_kernel<8, TAB, PW>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
   else
-    hipLaunchKernelGGL((conv_b16_kernel<4, TAB>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
+    hipLaunchKernelGGL((conv_b16_kernel<4, TAB, PW>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
+}
+
+// the pointwise fast path (conv_b16_kernel<.., PW>): 1x1x1, stride 1, no padding, frames of a multiple of 8 positions, 16-byte
+// aligned source
+static bool b16_pointwise(const cstp_conv_desc* d, const void* src) {
+  return d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
+         ((d->d * d->h * d->w) % 8) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (d->c % 16) == 0 && (d->k % 16) == 0;
 }
 
 static float* b16_slabs(void* ws, const cstp_conv_desc* d, const B16Geom& q) {
@@ -993,7 +1070,8 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
         for (int c = 0; c < d->kw; ++c, ++i) {
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
-    b16_launch_conv<false>(st, g, d->k, x, wp, y, slab, out_elems);
+    if (b16_pointwise(d, x)) b16_launch_conv<false, true>(st, g, d->k, x, wp, y, slab, out_elems);
+    else b16_launch_conv<false>(st, g, d->k, x, wp, y, slab, out_elems);
   }
   CSTP_LAUNCH_CHECK();
   if (g.ksplit > 1) {
@@ -1048,7 +1126,8 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
             }
         g.ntaps = i;
         g.ksplit = ksplit;
-        b16_launch_conv<false>(st, g, d->c, dy, wp, dx, slab, out_elems);
+        if (b16_pointwise(d, dy)) b16_launch_conv<false, true>(st, g, d->c, dy, wp, dx, slab, out_elems);
+        else b16_launch_conv<false>(st, g, d->c, dy, wp, dx, slab, out_elems);
         CSTP_LAUNCH_CHECK();
       }
   if (ksplit > 1) {
@@ -1097,7 +1176,9 @@ extern "C" int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_des
         for (int c = 0; c < d->kw; ++c, ++i) {
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
-    hipLaunchKernelGGL((wgrad_b16_kernel<false>), grid, dim3(256), 0, st, g, x, dy, slab);
+    // (pointwise layers: 16-byte row loads of x -- needs the 16-byte dY rows' condition on x too)
+    if (b16_pointwise(d, x) && g.vec8) hipLaunchKernelGGL((wgrad_b16_kernel<false, true>), grid, dim3(256), 0, st, g, x, dy, slab);
+    else hipLaunchKernelGGL((wgrad_b16_kernel<false>), grid, dim3(256), 0, st, g, x, dy, slab);
   }
   CSTP_LAUNCH_CHECK();
   if (S >= 16 && (size_t)d->k * g.K <= ((size_t)1 << 20))

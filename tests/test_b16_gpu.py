@@ -70,6 +70,9 @@ CONVS = [
     ((2, 3, 8, 32, 32), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),         # the stem: offset-table mode
     ((4, 128, 1, 1, 1), 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),        # one position per sample (layer4 of a small clip)
     ((2, 48, 2, 5, 5), 80, (1, 3, 3), (1, 1, 1), (0, 1, 1)),          # 5x5 frames: nothing is a multiple of 4 or 8
+    ((3, 48, 2, 6, 4), 80, (1, 1, 1), (1, 1, 1), (0, 0, 0)),          # pointwise path: ragged position tile, half K-tile, ragged rows
+    ((8, 1024, 1, 4, 4), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # pointwise path with split-K (one position tile, 32 K-tiles)
+    ((2, 64, 1, 7, 7), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),          # 1x1x1 on 7x7 frames (49 positions): NOT the pointwise path
 ]
 
 
