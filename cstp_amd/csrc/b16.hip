@@ -119,6 +119,7 @@ struct B16Conv {
   int contig;                      // four consecutive q are four consecutive, 8-byte aligned outputs of one sample
   int n_tiles_x, n_tiles_m;
   int ksplit;                      // > 1: blockIdx.y owns a slice of the K-tiles and leaves an fp32 partial tile in its slab
+  int wf32;                        // PW forward: `wp` is the fp32 weight tensor [M][Kw] itself (k contiguous): rounded on the fly, no pack launch
   int kh, kw;                      // TAB: kernel extent (for the offset table)
   short off[B16_MAXTAPS][4];       // per list entry: source offset (t, h, w), weight tap index
 };
@@ -268,10 +269,23 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
       const int wti = wok ? gi / gpt : 0, wcg = gi - wti * gpt;
       kel = taps[wti * 4 + 3] * g.Cs + wcg * 16 + (wc & 1) * 8;
     }
+    if (PW && g.wf32) {
+      // the 1x1x1 forward weight [kout][cin] already IS the row-major GEMM operand: eight floats -> eight bf16 here
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      wr[j] = make_uint4(0, 0, 0, 0);
-      if (wok) wr[j] = *reinterpret_cast<const uint4*>(wbase + j * wrow64 + (size_t)kel * 2);
+      for (int j = 0; j < NW; ++j) {
+        wr[j] = make_uint4(0, 0, 0, 0);
+        if (wok && m0 + wrow + 64 * j < g.M) {
+          const float4* pf = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wp) + (size_t)(m0 + wrow + 64 * j) * g.Kw + kel);
+          const float4 f0 = pf[0], f1 = pf[1];
+          wr[j] = make_uint4(pack_bf2(f0.x, f0.y), pack_bf2(f0.z, f0.w), pack_bf2(f1.x, f1.y), pack_bf2(f1.z, f1.w));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        wr[j] = make_uint4(0, 0, 0, 0);
+        if (wok) wr[j] = *reinterpret_cast<const uint4*>(wbase + j * wrow64 + (size_t)kel * 2);
+      }
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
@@ -689,62 +703,73 @@ b16_bn_reduce_kernel(const u16* __restrict__ x, const u16* __restrict__ y, const
   }
 }
 
-__global__ void b16_bn_finalize_fwd_kernel(const double* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                           float* __restrict__ running_mean, float* __restrict__ running_var, int c, int groups,
-                                           int nsplit, double count, float eps, float momentum, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, float2* __restrict__ ss) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  float rm = 0.f, rv = 0.f;
-  if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
-  for (int g = 0; g < groups; ++g) {
-    double s0 = 0.0, s1 = 0.0;
-    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
-    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
-    const double mu = s0 / count;
-    double var = s1 / count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    save_mean[g * c + ch] = (float)mu;
-    const float isf = (float)(1.0 / sqrt(var + (double)eps));
-    save_invstd[g * c + ch] = isf;
-    const float scl = isf * gamma[ch];
-    ss[g * c + ch] = make_float2(scl, beta[ch] - (float)mu * scl);
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
-    rv = (float)((1.0 - momentum) * rv + momentum * unb);
-  }
-  if (running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+// Sums of one (channel, group) from its `nsplit` partials: every lane of wave 0 calls it and gets the same two doubles (lanes
+// stride over the partials, xor-shuffle tree: one fixed order, so every block of the channel derives the same bits).
+__device__ __forceinline__ void b16_fold_partials(const double* __restrict__ part, int ch, int groups, int g, int nsplit, double& s0,
+                                                 double& s1) {
+  const int lane = threadIdx.x & 63;
+  const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+  s0 = 0.0; s1 = 0.0;
+  for (int j = lane; j < nsplit; j += 64) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
 }
 
-__global__ void b16_bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                           float* __restrict__ gsum, int c, int groups, int nsplit, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double t0 = 0.0, t1 = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    double s0 = 0.0, s1 = 0.0;
-    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
-    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
-    gsum[(g * c + ch) * 2 + 0] = (float)s0;
-    gsum[(g * c + ch) * 2 + 1] = (float)s1;
-    t0 += s0; t1 += s1;
-  }
-  dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
-  dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
+// (mean, invstd, scale, shift) of one (channel, group) from the forward sums
+__device__ __forceinline__ void b16_bn_stats_of(double s0, double s1, double count, float eps, float gamma, float beta, double& mu,
+                                               double& var, float& isf, float& sc, float& sh) {
+  mu = s0 / count;
+  var = s1 / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  isf = (float)(1.0 / sqrt(var + (double)eps));
+  sc = isf * gamma;
+  sh = beta - (float)mu * sc;
 }
 
 constexpr int B16_UNROLL = 4;     // 16-byte vectors per thread per block
 
-// y = bf16(act(fma(x, scale, shift) + residual)); one block = one chunk of one (sample, channel) row
+// y = bf16(act(fma(x, scale, shift) + residual)); one block = one chunk of one (sample, channel) row.  The statistics' finalize
+// is folded in (it was a launch of its own between the reduction and this pass: 106 launches per 3D-ResNet-50 step): wave 0 of
+// every block folds the partial sums of ITS (channel, group); the block of the channel's first row and chunk also writes
+// save_mean / save_invstd / scale_shift for every group and moves the running statistics, group after group.
 template <bool VEC8>
 __global__ void __launch_bounds__(256)
-b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, u16* __restrict__ y, const float2* __restrict__ ss,
-                        int c, int s, int npg, int relu, int chunks) {
+b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, u16* __restrict__ y, const double* __restrict__ part,
+                        int nsplit, int groups, double count, float eps, float momentum, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                        float* __restrict__ save_mean, float* __restrict__ save_invstd, float2* __restrict__ ss, int c, int s, int npg,
+                        int relu, int chunks) {
   constexpr int W = VEC8 ? 8 : 1;
+  __shared__ float s_ss[2];
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
-  const int ch = row % c, gc = (row / c) / npg * c + ch;
-  const float2 t2 = ss[gc];
-  const float sc = t2.x, sh = t2.y;
+  const int ch = row % c, grp = (row / c) / npg;
+  if (threadIdx.x < 64) {
+    const float ga = gamma[ch], be = beta[ch];
+    double s0, s1, mu, var;
+    float isf, scv, shv;
+    b16_fold_partials(part, ch, groups, grp, nsplit, s0, s1);
+    b16_bn_stats_of(s0, s1, count, eps, ga, be, mu, var, isf, scv, shv);
+    if (threadIdx.x == 0) { s_ss[0] = scv; s_ss[1] = shv; }
+    if (row == ch && chunk == 0) {                    // first sample of group 0: the channel's bookkeeping, once
+      float rm = 0.f, rv = 0.f;
+      if (running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+      for (int g = 0; g < groups; ++g) {
+        b16_fold_partials(part, ch, groups, g, nsplit, s0, s1);
+        b16_bn_stats_of(s0, s1, count, eps, ga, be, mu, var, isf, scv, shv);
+        if (threadIdx.x == 0) {
+          save_mean[g * c + ch] = (float)mu;
+          save_invstd[g * c + ch] = isf;
+          ss[g * c + ch] = make_float2(scv, shv);
+        }
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
+        rv = (float)((1.0 - momentum) * rv + momentum * unb);
+      }
+      if (threadIdx.x == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+    }
+  }
+  __syncthreads();
+  const float sc = s_ss[0], sh = s_ss[1];
   const size_t base = (size_t)row * s;
 #pragma unroll
   for (int u = 0; u < B16_UNROLL; ++u) {
@@ -772,20 +797,41 @@ b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, 
   }
 }
 
-// dx = bf16(gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))), dres = bf16(g), g = dy * mask
+// dx = bf16(gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))), dres = bf16(g), g = dy * mask.  The backward finalize is
+// folded in as in the forward pass: wave 0 folds the (sum g, sum g * xhat) partials of the block's (channel, group); the block
+// of the channel's first row and chunk writes dgamma / dbeta (summed over the groups; accumulate: +=).
 template <bool VEC8>
 __global__ void __launch_bounds__(256)
 b16_bn_apply_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, const u16* __restrict__ dy, const float* __restrict__ gamma,
-                        const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gsum,
-                        u16* __restrict__ dx, u16* __restrict__ dres, int c, int s, int npg, float inv_count, int relu,
-                        const float2* __restrict__ ss, int chunks) {
+                        const float* __restrict__ mean, const float* __restrict__ invstd, const double* __restrict__ part, int nsplit,
+                        int groups, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, u16* __restrict__ dx,
+                        u16* __restrict__ dres, int c, int s, int npg, float inv_count, int relu, const float2* __restrict__ ss,
+                        int chunks) {
   constexpr int W = VEC8 ? 8 : 1;
+  __shared__ float s_g[2];
   const bool remask = relu && (y == nullptr);
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
-  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const int ch = row % c, grp = (row / c) / npg, gc = grp * c + ch;
+  if (threadIdx.x < 64) {
+    double s0, s1;
+    b16_fold_partials(part, ch, groups, grp, nsplit, s0, s1);
+    if (threadIdx.x == 0) { s_g[0] = (float)s0; s_g[1] = (float)s1; }
+    if (row == ch && chunk == 0) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int g = 0; g < groups; ++g) {
+        b16_fold_partials(part, ch, groups, g, nsplit, s0, s1);
+        t0 += s0; t1 += s1;
+      }
+      if (threadIdx.x == 0) {       // the affine parameters are shared by the groups
+        dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+        dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
+      }
+    }
+  }
+  __syncthreads();
   const float mu = mean[gc], is = invstd[gc];
   const float k = gamma[ch] * is;
-  const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
+  const float mb = s_g[0] * inv_count, mg = s_g[1] * inv_count;
   float sc = 0.f, sh = 0.f;
   if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
   const size_t base = (size_t)row * s;
@@ -1037,8 +1083,11 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
   const int BM = d->k > 64 ? 128 : 64;
   const int Mp = (int)align_up((size_t)d->k, BM);
   u16* wp = reinterpret_cast<u16*>(ws);
-  hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * q.Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
-  CSTP_LAUNCH_CHECK();
+  const bool pw = !q.tab && b16_pointwise(d, x) && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+  if (!pw) {      // (pointwise forward: the kernel rounds the fp32 rows itself)
+    hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * q.Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
+    CSTP_LAUNCH_CHECK();
+  }
   B16Conv g;
   memset(&g, 0, sizeof(g));
   g.Nb = d->n; g.Cs = d->c;
@@ -1070,7 +1119,8 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
         for (int c = 0; c < d->kw; ++c, ++i) {
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
-    if (b16_pointwise(d, x)) b16_launch_conv<false, true>(st, g, d->k, x, wp, y, slab, out_elems);
+    if (pw) { g.wf32 = 1; b16_launch_conv<false, true>(st, g, d->k, x, w, y, slab, out_elems); }
+    else if (b16_pointwise(d, x)) b16_launch_conv<false, true>(st, g, d->k, x, wp, y, slab, out_elems);
     else b16_launch_conv<false>(st, g, d->k, x, wp, y, slab, out_elems);
   }
   CSTP_LAUNCH_CHECK();
@@ -1216,14 +1266,11 @@ extern "C" int cstp_b16_bn_forward_train(void* stream, const uint16_t* x, const 
   if (v8) hipLaunchKernelGGL((b16_bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
   else hipLaunchKernelGGL((b16_bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(b16_bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean, running_var,
-                     c, groups, ns, (double)npg * s, eps, momentum, gamma, beta, reinterpret_cast<float2*>(scale_shift));
-  CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, B16_UNROLL * 256 * (v8 ? 8 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  const float2* ss = reinterpret_cast<const float2*>(scale_shift);
-  if (v8) hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, ss, c, s, npg, relu, chunks);
-  else hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, ss, c, s, npg, relu, chunks);
+  float2* ss = reinterpret_cast<float2*>(scale_shift);
+  if (v8) hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, part, ns, groups, (double)npg * s, eps, momentum, gamma, beta, running_mean, running_var, save_mean, save_invstd, ss, c, s, npg, relu, chunks);
+  else hipLaunchKernelGGL((b16_bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, part, ns, groups, (double)npg * s, eps, momentum, gamma, beta, running_mean, running_var, save_mean, save_invstd, ss, c, s, npg, relu, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }
@@ -1239,7 +1286,6 @@ extern "C" int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint1
   hipStream_t st = as_stream(stream);
   const int npg = n / groups, ns = b16_bn_nsplit(npg, c);
   double* part = reinterpret_cast<double*>(ws);
-  float* gsum = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
   const float2* ss = reinterpret_cast<const float2*>(scale_shift);
   const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
                                     reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dresidual)) & 15) == 0;
@@ -1247,13 +1293,11 @@ extern "C" int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint1
   if (v8) hipLaunchKernelGGL((b16_bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss);
   else hipLaunchKernelGGL((b16_bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(b16_bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0);
-  CSTP_LAUNCH_CHECK();
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, B16_UNROLL * 256 * (v8 ? 8 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
-  if (v8) hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
-  else hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
+  if (v8) hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, part, ns, groups, dgamma, dbeta, accumulate ? 1 : 0, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
+  else hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, part, ns, groups, dgamma, dbeta, accumulate ? 1 : 0, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

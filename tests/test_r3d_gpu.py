@@ -124,8 +124,10 @@ def test_r3d_hip_matches_reference_golden(name):
         assert rel(ft(x2d, o_type="scratch").cpu().numpy(), r3d.ft_forward(fsd, x2, layers, False, "scratch").numpy()) < 1e-2
 
 
-def test_r3d_factory_and_pretrain_driver(tmp_path):
-    """generate_model(model_name='r3d_byol') + the pre-training driver for two epochs on synthetic clips."""
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_r3d_factory_and_pretrain_driver(tmp_path, act_dtype):
+    """generate_model(model_name='r3d_byol') + the pre-training driver for two epochs on synthetic clips; ``--act_dtype bf16``:
+    the same command line with bf16 activation storage (BASELINE configs[4])."""
     import importlib.util
     import os
     from cstp_amd.opts import parse_opts
@@ -136,7 +138,7 @@ def test_r3d_factory_and_pretrain_driver(tmp_path):
     opts = parse_opts(["--dataset", "synthetic", "--batch_size", "4", "--sample_duration", "8", "--sample_size", "56",
                        "--model_name", "r3d_byol", "--model_depth", "10", "--n_workers", "0", "--synthetic_len", "8",
                        "--result_path", str(tmp_path), "--task", "loss_com", "--loss_weight", "0.1", "1", "1", "1", "1",
-                       "--n_epochs", "2", "--learning_rate", "0.01", "--weight_decay", "5e-4"])
+                       "--n_epochs", "2", "--learning_rate", "0.01", "--weight_decay", "5e-4", "--act_dtype", act_dtype])
     mod.main(opts)
     rows = open(str(tmp_path / "synthetic" / "loss_com" / "synthetic_train_clip8modelr3d_byol10.log")).read().strip().split("\n")
     assert len(rows) == 3 and all(np.isfinite(float(r.split("\t")[1])) for r in rows[1:])
