@@ -743,6 +743,16 @@ b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, 
   __shared__ float s_ss[2];
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
   const int ch = row % c, grp = (row / c) / npg;
+  // the block's x values first: in flight while wave 0 folds the statistics
+  uint4 xv[B16_UNROLL];
+  if (VEC8) {
+#pragma unroll
+    for (int u = 0; u < B16_UNROLL; ++u) {
+      const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+      xv[u] = make_uint4(0, 0, 0, 0);
+      if (e < s) xv[u] = ld16_last(x + (size_t)row * s + e);
+    }
+  }
   if (threadIdx.x < 64) {
     const float ga = gamma[ch], be = beta[ch];
     double s0, s1, mu, var;
@@ -776,7 +786,7 @@ b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, 
     const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC8) {
-      const uint4 v = ld16_last(x + base + e);
+      const uint4 v = xv[u];
       uint4 r = make_uint4(0, 0, 0, 0);
       if (res != nullptr) r = *reinterpret_cast<const uint4*>(res + base + e);
       const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
@@ -812,6 +822,16 @@ b16_bn_apply_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, co
   const bool remask = relu && (y == nullptr);
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
   const int ch = row % c, grp = (row / c) / npg, gc = grp * c + ch;
+  // the block's x and dy values first: in flight while wave 0 folds the partial sums
+  uint4 xv[B16_UNROLL], gvv[B16_UNROLL];
+  if (VEC8) {
+#pragma unroll
+    for (int u = 0; u < B16_UNROLL; ++u) {
+      const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+      xv[u] = gvv[u] = make_uint4(0, 0, 0, 0);
+      if (e < s) { xv[u] = ld16_last(x + (size_t)row * s + e); gvv[u] = ld16_last(dy + (size_t)row * s + e); }
+    }
+  }
   if (threadIdx.x < 64) {
     double s0, s1;
     b16_fold_partials(part, ch, groups, grp, nsplit, s0, s1);
@@ -846,8 +866,8 @@ b16_bn_apply_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, co
     const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC8) {
-      const uint4 v = ld16_last(x + base + e);
-      const uint4 gv = ld16_last(dy + base + e);
+      const uint4 v = xv[u];
+      const uint4 gv = gvv[u];
       uint4 ov = make_uint4(0, 0, 0, 0);
       if (relu && !remask) ov = *reinterpret_cast<const uint4*>(y + base + e);
       const unsigned vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};

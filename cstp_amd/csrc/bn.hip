@@ -49,8 +49,10 @@ template <int MODE, bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                  const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int npg,
-                 int c, int s, int nsplit, int relu, const float2* __restrict__ ss) {
+                 int c, int s, int nsplit, int relu, const float2* __restrict__ ss, unsigned* __restrict__ cell = nullptr) {
   __shared__ double sm[16];
+  // (the absmax cell of the apply pass two launches on: absmax_fold_kernel takes the maximum into it)
+  if (cell != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *cell = 0;
   const int ch = blockIdx.x, grp = blockIdx.y / nsplit, j = blockIdx.y - grp * nsplit;
   double a0 = 0.0, a1 = 0.0;
   float mu = 0.f, is = 0.f;
@@ -213,27 +215,6 @@ bn_finalize_fwd_wide_kernel(const double* __restrict__ part, float* __restrict__
   if (lane == 0 && mm != nullptr && cell != nullptr && zmax != 0) atomicMax(cell, zmax);
 }
 
-// ---- stage 2 (backward): dgamma / dbeta ---------------------------------------------------------
-__global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ gsum, int c, int groups,
-                                       int nsplit, int accumulate, unsigned* __restrict__ cell) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch == 0 && cell != nullptr) *cell = 0;          // absmax_fold_kernel takes the maximum into it
-  if (ch >= c) return;
-  double t0 = 0.0, t1 = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    double s0 = 0.0, s1 = 0.0;
-    const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
-    for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
-    gsum[(g * c + ch) * 2 + 0] = (float)s0;     // per-group sum(g), sum(g*xhat) for the dx pass
-    gsum[(g * c + ch) * 2 + 1] = (float)s1;
-    t0 += s0; t1 += s1;
-  }
-  // the affine parameters are shared by the groups; accumulate: += into the caller's gradient buffers
-  dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
-  dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
-}
-
 // ---- stage 3: elementwise passes.  One block = one chunk of ONE (sample, channel) row, so the per-channel
 //      constants are block-uniform scalars and no per-element index division is needed (the flat-index form
 //      spent ~100 VALU instructions per float4 on 64-bit divisions and was VALU- rather than HBM-bound).
@@ -280,26 +261,99 @@ __global__ void __launch_bounds__(256) absmax_fold_kernel(const unsigned* __rest
   }
 }
 
+// The finalize step folded into the apply passes (it used to be a launch of its own between the reduction and the apply pass:
+// ~70 launches of a few microseconds per R(2+1)D-18 step on the critical chain).  `fin.part` != null: wave 0 of every block sums
+// the partials of ITS (channel, group) -- sequentially, in the order bn_finalize_*_kernel uses: the same bits -- while the
+// block's x loads are already in flight; the block of the channel's first row and chunk also does the channel's bookkeeping.
+struct BnFin {
+  const double* part;     // [c][groups][nsplit][2]; null = read the finished per-channel arrays instead
+  int nsplit, groups;
+  double count;
+  float eps, momentum;
+  float* running_mean;    // forward bookkeeping (may be null)
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float2* ss;             // may be null
+  float* dgamma;          // backward bookkeeping
+  float* dbeta;
+  int accumulate;
+};
+
+__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ part, int ch, int groups, int g, int nsplit, double& s0,
+                                               double& s1) {
+  const double* p = part + ((size_t)ch * groups + g) * nsplit * 2;
+  s0 = 0.0; s1 = 0.0;
+  for (int j = 0; j < nsplit; ++j) { s0 += p[2 * j]; s1 += p[2 * j + 1]; }
+}
+
 // forward: y = act((x-mean)*invstd*gamma + beta + residual)
 template <bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                     const float* __restrict__ invstd, int c, int s, int npg, int relu, int chunks,
-                    unsigned* __restrict__ cell) {
+                    unsigned* __restrict__ cell, const BnFin fin) {
   constexpr int W = VEC4 ? 4 : 1;
+  __shared__ float s_ss[2];
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
-  const int ch = row % c, gc = (row / c) / npg * c + ch;
-  const float sc = invstd[gc] * gamma[ch];
-  const float sh = beta[ch] - mean[gc] * sc;
+  const int ch = row % c, grp = (row / c) / npg, gc = grp * c + ch;
   const size_t base = (size_t)row * s;
+  // the block's x values first: in flight while wave 0 folds the statistics
+  float4 xv[BN_UNROLL];
+  float xs1[BN_UNROLL];
+#pragma unroll
+  for (int u = 0; u < BN_UNROLL; ++u) {
+    const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    xv[u] = make_float4(0.f, 0.f, 0.f, 0.f); xs1[u] = 0.f;
+    if (e < s) { if (VEC4) xv[u] = ld4_last(x + base + e); else xs1[u] = x[base + e]; }
+  }
+  float sc, sh;
+  if (fin.part != nullptr) {
+    if (threadIdx.x == 0) {
+      const float ga = gamma[ch], be = beta[ch];
+      double s0, s1;
+      bn_sum_partials(fin.part, ch, fin.groups, grp, fin.nsplit, s0, s1);
+      double mu = s0 / fin.count;
+      double var = s1 / fin.count - mu * mu;
+      if (var < 0.0) var = 0.0;
+      float isf = (float)(1.0 / sqrt(var + (double)fin.eps));
+      { const float scl = isf * ga; s_ss[0] = scl; s_ss[1] = be - (float)mu * scl; }
+      if (row == ch && chunk == 0) {                  // the channel's bookkeeping, once: exactly bn_finalize_fwd_kernel
+        float rm = 0.f, rv = 0.f;
+        if (fin.running_mean != nullptr) { rm = fin.running_mean[ch]; rv = fin.running_var[ch]; }
+        for (int g = 0; g < fin.groups; ++g) {
+          bn_sum_partials(fin.part, ch, fin.groups, g, fin.nsplit, s0, s1);
+          mu = s0 / fin.count;
+          var = s1 / fin.count - mu * mu;
+          if (var < 0.0) var = 0.0;
+          fin.save_mean[g * c + ch] = (float)mu;
+          isf = (float)(1.0 / sqrt(var + (double)fin.eps));
+          fin.save_invstd[g * c + ch] = isf;
+          if (fin.ss != nullptr) {
+            const float scl = isf * ga;
+            fin.ss[g * c + ch] = make_float2(scl, be - (float)mu * scl);
+          }
+          const double unb = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+          rm = (float)((1.0 - fin.momentum) * rm + fin.momentum * mu);      // group after group, like successive calls
+          rv = (float)((1.0 - fin.momentum) * rv + fin.momentum * unb);
+        }
+        if (fin.running_mean != nullptr) { fin.running_mean[ch] = rm; fin.running_var[ch] = rv; }
+      }
+    }
+    __syncthreads();
+    sc = s_ss[0]; sh = s_ss[1];
+  } else {
+    sc = invstd[gc] * gamma[ch];
+    sh = beta[ch] - mean[gc] * sc;
+  }
   unsigned mx = 0;
 #pragma unroll
   for (int u = 0; u < BN_UNROLL; ++u) {
     const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC4) {
-      float4 v = ld4_last(x + base + e);
+      float4 v = xv[u];
       v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
       if (res != nullptr) {
         const float4 r = *reinterpret_cast<const float4*>(res + base + e);
@@ -309,7 +363,7 @@ bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
       st4(y + base + e, v);
       mx = umax4(mx, v);
     } else {
-      float v = x[base + e] * sc + sh;
+      float v = xs1[u] * sc + sh;
       if (res != nullptr) v += res[base + e];
       if (relu) v = fmaxf(v, 0.f);
       y[base + e] = v;
@@ -327,25 +381,59 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                     const float* __restrict__ gsum, float* __restrict__ dx,
                     float* __restrict__ dres, int c, int s, int npg, float inv_count, int relu,
-                    const float2* __restrict__ ss, int chunks, unsigned* __restrict__ cell) {
+                    const float2* __restrict__ ss, int chunks, unsigned* __restrict__ cell, const BnFin fin) {
   constexpr int W = VEC4 ? 4 : 1;
+  __shared__ float s_g[2];
   unsigned mx = 0;
   const bool remask = relu && (y == nullptr);
   const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
-  const int ch = row % c, gc = (row / c) / npg * c + ch;
+  const int ch = row % c, grp = (row / c) / npg, gc = grp * c + ch;
+  const size_t base = (size_t)row * s;
+  // the block's x and dy values first: in flight while thread 0 folds the (sum g, sum g * xhat) partials
+  float4 xv[BN_UNROLL], gv[BN_UNROLL];
+  float xs1[BN_UNROLL], gs1[BN_UNROLL];
+#pragma unroll
+  for (int u = 0; u < BN_UNROLL; ++u) {
+    const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    xv[u] = gv[u] = make_float4(0.f, 0.f, 0.f, 0.f); xs1[u] = gs1[u] = 0.f;
+    if (e < s) {
+      if (VEC4) { xv[u] = ld4_last(x + base + e); gv[u] = ld4_last(dy + base + e); }
+      else { xs1[u] = x[base + e]; gs1[u] = dy[base + e]; }
+    }
+  }
+  float sum_g, sum_gx;
+  if (fin.part != nullptr) {
+    if (threadIdx.x == 0) {
+      double s0, s1;
+      bn_sum_partials(fin.part, ch, fin.groups, grp, fin.nsplit, s0, s1);
+      s_g[0] = (float)s0; s_g[1] = (float)s1;
+      if (row == ch && chunk == 0) {                  // dgamma / dbeta of the channel, once: exactly bn_finalize_bwd_kernel
+        double t0 = 0.0, t1 = 0.0;
+        for (int g = 0; g < fin.groups; ++g) {
+          bn_sum_partials(fin.part, ch, fin.groups, g, fin.nsplit, s0, s1);
+          t0 += s0; t1 += s1;
+        }
+        fin.dbeta[ch] = (fin.accumulate ? fin.dbeta[ch] : 0.f) + (float)t0;
+        fin.dgamma[ch] = (fin.accumulate ? fin.dgamma[ch] : 0.f) + (float)t1;
+      }
+    }
+    __syncthreads();
+    sum_g = s_g[0]; sum_gx = s_g[1];
+  } else {
+    sum_g = gsum[gc * 2]; sum_gx = gsum[gc * 2 + 1];
+  }
   const float mu = mean[gc], is = invstd[gc];
   const float k = gamma[ch] * is;
-  const float mb = gsum[gc * 2] * inv_count, mg = gsum[gc * 2 + 1] * inv_count;
+  const float mb = sum_g * inv_count, mg = sum_gx * inv_count;
   float sc = 0.f, sh = 0.f;
   if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
-  const size_t base = (size_t)row * s;
 #pragma unroll
   for (int u = 0; u < BN_UNROLL; ++u) {
     const int e = (chunk * BN_UNROLL * 256 + u * 256 + threadIdx.x) * W;
     if (e >= s) continue;
     if (VEC4) {
-      const float4 v = ld4_last(x + base + e);
-      float4 g = ld4_last(dy + base + e);
+      const float4 v = xv[u];
+      float4 g = gv[u];
       if (remask) {
         g.x = (v.x * sc + sh) > 0.f ? g.x : 0.f; g.y = (v.y * sc + sh) > 0.f ? g.y : 0.f;
         g.z = (v.z * sc + sh) > 0.f ? g.z : 0.f; g.w = (v.w * sc + sh) > 0.f ? g.w : 0.f;
@@ -363,11 +451,11 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
       st4(dx + base + e, o);
       mx = umax4(mx, o);
     } else {
-      float g = dy[base + e];
-      if (remask) { if (!((x[base + e] * sc + sh) > 0.f)) g = 0.f; }
+      float g = gs1[u];
+      if (remask) { if (!((xs1[u] * sc + sh) > 0.f)) g = 0.f; }
       else if (relu && !(y[base + e] > 0.f)) g = 0.f;
       if (dres != nullptr) dres[base + e] = g;
-      const float o = k * (g - mb - (x[base + e] - mu) * is * mg);
+      const float o = k * (g - mb - (xs1[u] - mu) * is * mg);
       dx[base + e] = o;
       const unsigned a = abs_bits(o);
       mx = mx > a ? mx : a;
@@ -546,25 +634,27 @@ static int bn_forward_train_impl(void* stream, const float* x, const float* resi
   const int ns = bn_nsplit(npg, c);
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
+  BnFin fin;
+  memset(&fin, 0, sizeof(fin));
   if (pre_part != nullptr) {
     // the producing convolution left the sums (cstp_conv3d_forward_bnstats): no pass over x, a wave per channel folds them
     hipLaunchKernelGGL(bn_finalize_fwd_wide_kernel, dim3(c), dim3(64), 0, st, pre_part, save_mean, save_invstd, running_mean,
                        running_var, c, groups, pre_nsplit, (double)npg * s, eps, momentum, gamma, beta,
                        reinterpret_cast<float2*>(scale_shift), y_absmax, nullptr, 0);
   } else {
-    if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
-    else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr);
-    CSTP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, save_mean, save_invstd, running_mean,
-                       running_var, c, groups, ns, (double)npg * s, eps, momentum, gamma, beta,
-                       reinterpret_cast<float2*>(scale_shift), y_absmax);
+    // statistics pass; its finalize is folded into the apply pass below (BnFin), the absmax cell is zeroed here
+    if (v4) hipLaunchKernelGGL((bn_reduce_kernel<0, true>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr, y_absmax);
+    else hipLaunchKernelGGL((bn_reduce_kernel<0, false>), rgrid, dim3(256), 0, st, x, x, x, nullptr, nullptr, part, npg, c, s, ns, 0, nullptr, y_absmax);
+    fin.part = part; fin.nsplit = ns; fin.groups = groups; fin.count = (double)npg * s; fin.eps = eps; fin.momentum = momentum;
+    fin.running_mean = running_mean; fin.running_var = running_var; fin.save_mean = save_mean; fin.save_invstd = save_invstd;
+    fin.ss = reinterpret_cast<float2*>(scale_shift);
   }
   CSTP_LAUNCH_CHECK();
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   unsigned* slots = y_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots);
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots, fin);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, save_mean, save_invstd, c, s, npg, relu, chunks, slots, fin);
   CSTP_LAUNCH_CHECK();
   if (slots != nullptr) {
     hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, y_absmax);
@@ -622,8 +712,10 @@ extern "C" int cstp_bn_forward_eval_am(void* stream, const float* x, const float
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   // one "group" spanning the whole batch: the apply kernel reads mean/invstd at [channel]
-  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots);
-  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots);
+  BnFin nofin;
+  memset(&nofin, 0, sizeof(nofin));
+  if (v4) hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots, nofin);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), agrid, dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, invstd, c, s, n, relu, chunks, slots, nofin);
   CSTP_LAUNCH_CHECK();
   if (slots != nullptr) {
     hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, y_absmax);
@@ -689,17 +781,19 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
                                          align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
-  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2);
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax);
+  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax);
   CSTP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(64), 0, st, part, dgamma, dbeta, gsum, c, groups, ns, accumulate ? 1 : 0, dx_absmax);
-  CSTP_LAUNCH_CHECK();
+  // (the finalize -- per-group sums for the dx pass, dgamma / dbeta -- is folded into the apply pass: BnFin)
+  BnFin fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.part = part; fin.nsplit = ns; fin.groups = groups; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.accumulate = accumulate ? 1 : 0;
   const float inv_count = (float)(1.0 / ((double)npg * s));
   const int chunks = cdiv(s, BN_UNROLL * 256 * (v4 ? 4 : 1));
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   unsigned* slots = dx_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
-  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots);
-  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots);
+  if (v4) hipLaunchKernelGGL((bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots, fin);
+  else hipLaunchKernelGGL((bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, gsum, dx, dresidual, c, s, npg, inv_count, relu, ss2, chunks, slots, fin);
   CSTP_LAUNCH_CHECK();
   if (slots != nullptr) {
     hipLaunchKernelGGL(absmax_fold_kernel, dim3(FOLD_BLOCKS), dim3(256), 0, st, slots, (int)agrid.x * 4, dx_absmax);
