@@ -121,6 +121,7 @@ SIGNATURES = {
                                             c_float, c_float, c_int32, _P, c_size_t]),
     "cstp_b16_bn_backward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, _P, c_size_t, c_int32]),
+    "cstp_b16_bn_forward_eval": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, c_int32]),
     "cstp_b16_maxpool3d_forward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32),
                                              POINTER(c_int32), POINTER(c_int32)]),
     "cstp_b16_maxpool3d_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32),

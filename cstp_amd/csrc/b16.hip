@@ -807,6 +807,44 @@ b16_bn_apply_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, 
   }
 }
 
+// eval mode (model.eval(): validation / test of the fine-tuned network): the running statistics are the statistics
+template <bool VEC8>
+__global__ void __launch_bounds__(256)
+b16_bn_eval_kernel(const u16* __restrict__ x, const u16* __restrict__ res, u16* __restrict__ y, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                   int c, int s, float eps, int relu, int chunks) {
+  constexpr int W = VEC8 ? 8 : 1;
+  const int row = blockIdx.x / chunks, chunk = blockIdx.x - row * chunks;
+  const int ch = row % c;
+  const float sc = gamma[ch] / sqrtf(running_var[ch] + eps);
+  const float sh = beta[ch] - running_mean[ch] * sc;
+  const size_t base = (size_t)row * s;
+#pragma unroll
+  for (int u = 0; u < B16_UNROLL; ++u) {
+    const int e = (chunk * B16_UNROLL * 256 + u * 256 + threadIdx.x) * W;
+    if (e >= s) continue;
+    if (VEC8) {
+      const uint4 v = ld16_last(x + base + e);
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (res != nullptr) r = *reinterpret_cast<const uint4*>(res + base + e);
+      const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w};
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = __builtin_fmaf(bflo(vv[q]), sc, sh) + bflo(rr[q]), b = __builtin_fmaf(bfhi(vv[q]), sc, sh) + bfhi(rr[q]);
+        if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+        o[q] = pack_bf2(a, b);
+      }
+      *reinterpret_cast<uint4*>(y + base + e) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      float a = __builtin_fmaf(bf2f(x[base + e]), sc, sh);
+      if (res != nullptr) a += bf2f(res[base + e]);
+      if (relu) a = fmaxf(a, 0.f);
+      y[base + e] = f2bf(a);
+    }
+  }
+}
+
 // dx = bf16(gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))), dres = bf16(g), g = dy * mask.  The backward finalize is
 // folded in as in the forward pass: wave 0 folds the (sum g, sum g * xhat) partials of the block's (channel, group); the block
 // of the channel's first row and chunk writes dgamma / dbeta (summed over the groups; accumulate: +=).
@@ -1318,6 +1356,20 @@ extern "C" int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint1
   const dim3 agrid((unsigned)((size_t)n * c * chunks));
   if (v8) hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<true>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, part, ns, groups, dgamma, dbeta, accumulate ? 1 : 0, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
   else hipLaunchKernelGGL((b16_bn_apply_bwd_kernel<false>), agrid, dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, part, ns, groups, dgamma, dbeta, accumulate ? 1 : 0, dx, dresidual, c, s, npg, inv_count, relu, ss, chunks);
+  CSTP_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cstp_b16_bn_forward_eval(void* stream, const uint16_t* x, const uint16_t* residual, uint16_t* y, const float* gamma,
+                                        const float* beta, const float* running_mean, const float* running_var, int32_t n, int32_t c,
+                                        int32_t s, float eps, int32_t relu) {
+  CSTP_REQUIRE(x && y && gamma && beta && running_mean && running_var, "null argument");
+  CSTP_REQUIRE(n > 0 && c > 0 && s > 0, "bad shape");
+  const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  const int chunks = cdiv(s, B16_UNROLL * 256 * (v8 ? 8 : 1));
+  const dim3 agrid((unsigned)((size_t)n * c * chunks));
+  if (v8) hipLaunchKernelGGL((b16_bn_eval_kernel<true>), agrid, dim3(256), 0, as_stream(stream), x, residual, y, gamma, beta, running_mean, running_var, c, s, eps, relu, chunks);
+  else hipLaunchKernelGGL((b16_bn_eval_kernel<false>), agrid, dim3(256), 0, as_stream(stream), x, residual, y, gamma, beta, running_mean, running_var, c, s, eps, relu, chunks);
   CSTP_LAUNCH_CHECK();
   return 0;
 }

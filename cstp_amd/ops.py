@@ -626,6 +626,18 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, residual=None, re
                                     or (residual is not None and residual.requires_grad)):
         raise _lib.CstpError("eval-mode BatchNorm is forward-only: call it under torch.no_grad() (as the reference's "
                              "validation/test loops do)")
+    if x.dtype == torch.bfloat16:          # the bf16-storage path
+        x = _req16(x, "batch_norm input")
+        n, c = x.shape[0], x.shape[1]
+        res = None if residual is None else _req16(residual, "residual")
+        if res is not None and res.shape != x.shape:
+            raise _lib.CstpError("residual shape %s != input shape %s" % (tuple(res.shape), tuple(x.shape)))
+        y = torch.empty_like(x)
+        check(lib.cstp_b16_bn_forward_eval(_stream(), x.data_ptr(), _ptr(res), y.data_ptr(), _req(gamma, "weight").data_ptr(),
+                                           _req(beta, "bias").data_ptr(), _req(running_mean, "running_mean").data_ptr(),
+                                           _req(running_var, "running_var").data_ptr(), n, c, x.numel() // (n * c), float(eps),
+                                           1 if relu else 0), "cstp_b16_bn_forward_eval")
+        return y
     x = _req(x, "batch_norm input")
     n, c = x.shape[0], x.shape[1]
     s = x.numel() // (n * c)

@@ -21,7 +21,7 @@ encoder's output": ``view(-1, F)``; Predictor Linear(F, 4096) -> BN1d -> ReLU ->
 with the F-wide target feature); overlap_spa / overlap_tem Linear(2F, 5); pb_cls / rot_cls Linear(F, 4); classify_bn
 BatchNorm1d(F); classify Linear(F, n_classes).  For F = 512 this is the reference, key for key.
 
-bf16 STORAGE (configs[4] says bf16; ``opts.act_dtype == "bf16"``, pre-training only): the clip is rounded to bf16 once and every
+bf16 STORAGE (configs[4] says bf16; ``opts.act_dtype == "bf16"``; pre-training, and the fine-tune / validation / test forwards): the clip is rounded to bf16 once and every
 5-D activation / activation gradient of the encoders is bf16 in HBM, arithmetic fp32, parameters / gradients / statistics /
 pooled features / heads / losses fp32 -- the spec in include/cstp_hip.h ("bf16-STORAGE path") and csrc/b16.hip, restated by
 oracle/r3d_byol_oracle.py (storage="bf16").  cstp_amd.ops dispatches on the dtype of the activation tensor.
@@ -186,9 +186,6 @@ class R3DBYOL(ByolBase):
         act = getattr(opts, "act_dtype", "fp32") or "fp32"
         if act not in ("fp32", "bf16"):
             raise ValueError("--act_dtype %r: fp32 | bf16" % (act,))
-        if act == "bf16" and not pretrain:
-            raise NotImplementedError("--act_dtype bf16 covers the pre-training step (train-mode BatchNorm); fine-tune / test "
-                                      "run with fp32 activations")
         self.act_bf16 = act == "bf16"
         kw = dict(sample_size=opts.sample_size, sample_duration=opts.sample_duration, shortcut_type=opts.sc_type,
                   num_classes=opts.n_classes)
@@ -273,7 +270,7 @@ class R3DBYOL(ByolBase):
         if o_type in ["ft_fc", "ft_all", "test", "scratch"]:
             if self.pretrain:
                 raise AttributeError("R3DBYOL(pretrain=True) has no classify: o_type=%r needs pretrain=False" % o_type)
-            online_feat = self.online_net(x1)
+            online_feat = self.online_net(ops.to_bf16(x1) if self.act_bf16 else x1)     # pooled features are fp32 either way
             if o_type != "scratch" and self.cls_bn:             # :420-428 vs :429-432
                 online_feat = ops.l2_normalize(online_feat)
                 online_feat = self.classify_bn(online_feat)

@@ -376,6 +376,10 @@ int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint16_t* y, con
                          const float* save_mean, const float* save_invstd, const float* scale_shift, uint16_t* dx,
                          uint16_t* dresidual, float* dgamma, float* dbeta, int32_t n, int32_t c, int32_t s, int32_t groups,
                          int32_t relu, void* ws, size_t ws_bytes, int32_t accumulate);
+/* every BatchNorm3d under model.eval() (main_ft_mp.py:261-262, test.py:75-81) on bf16: as cstp_bn_forward_eval. */
+int cstp_b16_bn_forward_eval(void* stream, const uint16_t* x, const uint16_t* residual, uint16_t* y, const float* gamma,
+                             const float* beta, const float* running_mean, const float* running_var, int32_t n, int32_t c,
+                             int32_t s, float eps, int32_t relu);
 /* nn.MaxPool3d r3d_byol.py:158 on bf16 (same tie rule and argmax as cstp_maxpool3d_forward). */
 int cstp_b16_maxpool3d_forward(void* stream, const uint16_t* x, uint16_t* y, int32_t* argmax, int32_t rows, int32_t d, int32_t h,
                                int32_t w, const int32_t* kernel3, const int32_t* stride3, const int32_t* pad3);

@@ -117,6 +117,7 @@ def test_bf16_storage_entry_points_fail_cleanly_before_any_hip_call():
          b"workspace too small"),
         ("cstp_b16_bn_backward", (None, one, None, one, one, one, one, None, one, None, one, one, 4, 8, 16, 1, 1, one, 1 << 20, 0),
          b"ReLU mask needs y or scale_shift"),
+        ("cstp_b16_bn_forward_eval", (None, one, None, one, one, one, one, None, 4, 8, 16, f(1e-5), 0), b"null argument"),
         ("cstp_b16_maxpool3d_forward", (None, one, one, one, 4, 8, 8, 8, (ctypes.c_int32 * 3)(3, 3, 3), (ctypes.c_int32 * 3)(2, 2, 2),
                                         (ctypes.c_int32 * 3)(2, 2, 2)), b"bad pooling geometry"),
         ("cstp_b16_avgpool_forward", (None, None, one, 4, 8), b"bad argument"),

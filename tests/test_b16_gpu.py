@@ -357,3 +357,49 @@ def test_r3d_bf16_step_against_the_reference_fp64_goldens(name, logits_bar):
         assert e["grad_norm"] < 5e-2, e
     finally:
         r3d.for_depth(18)
+
+
+@pytest.mark.parametrize("name", ["r3d_10_small", "r3d_18_small"])
+def test_r3d_bf16_finetune_wrapper_train_and_eval_mode(name):
+    """The fine-tune / test forwards (r3d_byol.py:420-428) with bf16 activation storage: train-mode logits and -- through the
+    eval-mode BatchNorm kernel on bf16, cstp_b16_bn_forward_eval -- model.eval() logits, against the oracle of the same spec and
+    against the reference's fp64 goldens.  Bars from the spec's own sensitivity, measured with the CPU oracle (the train-mode
+    logits pass a BatchNorm1d over FOUR samples, which amplifies every rounding flip): the oracle run with fp32 instead of fp64
+    between the rounding points is 0.9e-2 (depth 10) / 2.1e-2 (depth 18) of the largest logit from its fp64 run, and the spec
+    sits 1.9e-2 / 4.6e-2 from the reference goldens -- train-mode bars 5e-2 (oracle) and 1e-1 (goldens); eval mode (running
+    statistics, nothing amplified): 1e-3."""
+    import os
+    from cstp_amd.r3d_byol import R3DBYOL
+    from oracle import r21d_byol_oracle as orc
+    from oracle import r3d_byol_oracle as r3d
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
+    depth, b, t, hw, _ = [int(v) for v in g["meta"]]
+    layers = r3d.for_depth(depth)
+    try:
+        fsd = r3d.closed_form_state(r3d.ft_spec(layers, 11), torch.float32)
+        x1, x2, _ = orc.closed_form_clips(b, t, hw, torch.float32)
+        ft = R3DBYOL(pretrain=False, cls_bn=True, opts=_opts(depth, t, hw, k=11))
+        res = ft.load_state_dict(fsd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        ft.cuda().train()
+        r3d.set_storage("bf16")
+        o64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in fsd.items()}
+        want_train = r3d.ft_forward(o64, x1.double(), layers, True, "ft_all")
+        want_eval = r3d.ft_forward(o64, x2.double(), layers, False, "test")         # (running statistics moved by the train call)
+        r3d.set_storage(None)
+
+        def rel(a, bb):
+            a, bb = np.asarray(a, dtype=np.float64), np.asarray(bb, dtype=np.float64)
+            return float(np.abs(a - bb).max() / max(np.abs(bb).max(), 1e-30))
+
+        with torch.no_grad():
+            got_train = ft(x1.cuda(), o_type="ft_all").cpu().numpy()
+            ft.eval()
+            got_eval = ft(x2.cuda(), o_type="test").cpu().numpy()
+        e = (rel(got_train, want_train.numpy()), rel(got_eval, want_eval.numpy()), rel(got_train, g["ft.train_logits"]),
+             rel(got_eval, g["ft.eval_logits"]))
+        print("%s bf16 fine-tune wrapper: train / eval vs the bf16 oracle %.2e %.2e; vs the reference fp64 golden %.2e %.2e" % ((name,) + e))
+        assert e[0] < 5e-2 and e[1] < 1e-3 and e[2] < 1e-1 and e[3] < 1e-3, e
+    finally:
+        r3d.set_storage(None)
+        r3d.for_depth(18)

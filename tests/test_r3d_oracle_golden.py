@@ -139,7 +139,7 @@ def test_r3d_50_backbone_oracle_matches_reference_modules(fixture):
 def test_bf16_storage_spec_of_the_oracle_and_the_act_dtype_switch():
     """The bf16-storage restatement (oracle set_storage("bf16"), parity-unpinned spec of include/cstp_hip.h): features are means of
     bf16-representable activations, the mode leaves the unrounded path untouched, stays within bf16's distance of it, and rounds the
-    gradients of activations but not of weights; the product refuses --act_dtype bf16 where it has no kernels for it."""
+    gradients of activations but not of weights; the product's --act_dtype switch."""
     import argparse
     from cstp_amd.opts import parse_opts
     from cstp_amd.r3d_byol import R3DBYOL
@@ -180,8 +180,7 @@ def test_bf16_storage_spec_of_the_oracle_and_the_act_dtype_switch():
     assert parse_opts([]).act_dtype == "fp32" and parse_opts(["--act_dtype", "bf16"]).act_dtype == "bf16"
     ns = argparse.Namespace(model_depth=10, sample_size=32, sample_duration=4, sc_type="B", n_classes=11, act_dtype="bf16")
     assert R3DBYOL(pretrain=True, opts=ns).act_bf16 is True
-    with pytest.raises(NotImplementedError):
-        R3DBYOL(pretrain=False, cls_bn=True, opts=ns)
+    assert R3DBYOL(pretrain=False, cls_bn=True, opts=ns).act_bf16 is True        # fine-tune / test forwards too
     ns.act_dtype = "fp8"
     with pytest.raises(ValueError):
         R3DBYOL(pretrain=True, opts=ns)
