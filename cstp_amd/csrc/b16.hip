@@ -128,8 +128,10 @@ struct B16Conv {
 // the 16 rows x one chunk of a fragment read then cover all 64 banks once.
 __device__ __forceinline__ int b16_slot(int row, int c) { return row * 4 + (c ^ ((row >> 2) & 3)); }
 
-// PW ("pointwise": the 1x1x1 stride-1 layers -- two thirds of a Bottleneck network's convolutions -- with frames that are multiples
-// of 8 positions): no halo and no taps, so a thread gathers EIGHT consecutive positions of one channel with one 16-byte load
+// PW ("pointwise" first, then every stride-1 layer whose rows are multiples of 8 positions): a thread gathers EIGHT consecutive
+// positions of one channel with one 16-byte load -- for a tap that shifts the row by one element plus the neighbouring dword,
+// the eight values then come out of two v_alignbit per dword pair, and an element beyond the row's end is an out-of-range
+// load = 0; a tap row outside the frame is an out-of-range offset for the whole octet --
 // (two per thread and K-tile instead of sixteen 2-byte loads: the generic loop is bound by the number of gather instructions),
 // the LDS image is k-major (32 channel rows of 128 positions, 288-byte row stride) and the position fragments come out of it
 // k-contiguous through the transposing ds_read_b64_tr_b16 (lane 4q + p of a 16-lane group supplies row q / positions
@@ -162,8 +164,7 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const int n0 = ntile * 128, m0 = mtile * BM;
   const int HWs = g.Hs * g.Ws, DHWs = g.Ds * HWs;
 
-  if (PW) {
-  } else if (!TAB) {
+  if (!TAB) {
     if (t < g.ntaps * 4) taps[t] = g.off[t >> 2][t & 3];
   } else {
     const int khw = g.kh * g.kw, kreal = g.ntaps * g.Cs;
@@ -193,7 +194,8 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   const __amdgpu_buffer_rsrc_t rs_src = b16_rsrc(src, (unsigned)((size_t)g.Nb * g.Cs * DHWs * 2));
   const int gpt = (TAB || PW) ? 1 : (g.Cs >> 4);                        // 16-channel groups per tap
   const int ngroups = (TAB || PW) ? (g.Kw >> 4) : g.ntaps * gpt;
-  const int ntiles_all = (ngroups + 1) >> 1;
+  const int cblocks = (g.Cs + 31) >> 5;                                 // PW: 32-channel blocks per tap
+  const int ntiles_all = PW ? g.ntaps * cblocks : (ngroups + 1) >> 1;
   // split-K: layers with few positions (a 7x7 frame: 4 position tiles) would leave most of the chip idle and every block
   // latency-bound on a long K loop -- blockIdx.y takes K-tiles [kt_lo, kt_hi) and the partial tiles are summed by
   // b16_sum_slabs_kernel (deterministic: no atomics)
@@ -210,17 +212,24 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
 
   u16 xr[16];
   u32x4v xq[PW ? 2 : 1];
+  unsigned xe[2] = {0, 0};                             // PW: the neighbouring dword of an octet under a +-1 tap
   uint4 wr[NW];
   // PW: my channel row of the K-tile and my two octets of positions (lanes 0..7 of a row: 128 contiguous bytes)
   const int krow = t >> 3;
   unsigned pw_off[2] = {B16_OOB, B16_OOB};
+  int pw_d[2] = {0, 0}, pw_h[2] = {0, 0}, pw_w[2] = {0, 0};
+  int last_dw = 0;
   if (PW) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int Po = n0 + 8 * ((t & 7) + 8 * e);
       if (Po < npos) {
-        const int nbo = Po / npq, pos = Po - nbo * npq;
-        pw_off[e] = (unsigned)(((size_t)nbo * g.Cs * npq + pos) * 2);
+        int n = Po;
+        pw_w[e] = n % g.Wq; n /= g.Wq;
+        pw_h[e] = n % g.Hq; n /= g.Hq;
+        pw_d[e] = n % g.Dq; const int nbo = n / g.Dq;
+        // (source coordinate = position + tap offset: the source may be larger than the output by the padding it lacks)
+        pw_off[e] = (unsigned)((((size_t)nbo * g.Cs * g.Ds + pw_d[e]) * HWs + pw_h[e] * g.Ws + pw_w[e]) * 2);
       }
     }
   }
@@ -229,13 +238,26 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
     // X
     unsigned vo = B16_OOB;
     if (PW) {
-      const int c = kt * 32 + krow;
-      const unsigned coff = (unsigned)c * cstride;
+      const int pti = kt / cblocks, cb = kt - pti * cblocks;
+      const int dt = taps[pti * 4 + 0], dh = taps[pti * 4 + 1], dw = taps[pti * 4 + 2];
+      const int c = cb * 32 + krow;
+      const unsigned coff = (unsigned)c * cstride + (unsigned)((dt * HWs + dh * g.Ws) * 2);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned v = (c < g.Cs && pw_off[e] != B16_OOB) ? pw_off[e] + coff : B16_OOB;
+        const bool ok = kt < kt_hi && c < g.Cs && pw_off[e] != B16_OOB && (unsigned)(pw_d[e] + dt) < (unsigned)g.Ds &&
+                        (unsigned)(pw_h[e] + dh) < (unsigned)g.Hs;
+        const unsigned v = ok ? pw_off[e] + coff : B16_OOB;
         xq[e] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_src, v, 0, 0));
+        if (dw != 0) {                                 // (block-uniform)
+          unsigned ve = B16_OOB;
+          if (ok) {
+            if (dw < 0) { if (pw_w[e] > 0) ve = v - 4u; }
+            else if (pw_w[e] + 8 < g.Ws) ve = v + 16u;
+          }
+          xe[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_src, ve, 0, 0);
+        }
       }
+      last_dw = dw;
     } else if (TAB) {
       const int k0 = (kt * 2 + g2) * 16;
       if (pvalid && k0 < g.Kw) {
@@ -260,7 +282,11 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
     // W
     int kel;                                                            // element offset of my chunk inside the packed row
     bool wok;
-    if (TAB || PW) {
+    if (PW) {
+      const int pti = kt / cblocks, cb = kt - pti * cblocks;
+      wok = kt < kt_hi && cb * 32 + wc * 8 < g.Cs;
+      kel = taps[(wok ? pti : 0) * 4 + 3] * g.Cs + cb * 32 + wc * 8;
+    } else if (TAB) {
       kel = kt * 32 + wc * 8;
       wok = kel < g.Kw;
     } else {
@@ -297,8 +323,16 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
   auto stage = [&](int buf) __attribute__((always_inline)) {
     if constexpr (PW) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        Xs[buf][krow * PW_ROW + (t & 7) + 8 * e] = make_uint4(xq[e][0], xq[e][1], xq[e][2], xq[e][3]);
+      for (int e = 0; e < 2; ++e) {
+        u32x4v q = xq[e];
+        if (last_dw < 0)           // element i of the octet = source element i - 1: the previous dword's high half comes in front
+          q = u32x4v{__builtin_amdgcn_alignbit(q[0], xe[e], 16), __builtin_amdgcn_alignbit(q[1], q[0], 16),
+                     __builtin_amdgcn_alignbit(q[2], q[1], 16), __builtin_amdgcn_alignbit(q[3], q[2], 16)};
+        else if (last_dw > 0)      // ... = source element i + 1: the next dword's low half closes the octet
+          q = u32x4v{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                     __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(xe[e], q[3], 16)};
+        Xs[buf][krow * PW_ROW + (t & 7) + 8 * e] = make_uint4(q[0], q[1], q[2], q[3]);
+      }
     } else {
       uint4 a, b;
       a.x = xr[0] | ((unsigned)xr[1] << 16); a.y = xr[2] | ((unsigned)xr[3] << 16);
@@ -1117,11 +1151,18 @@ static void b16_launch_conv(hipStream_t st, const B16Conv& g, int M, const uint1
     hipLaunchKernelGGL((conv_b16_kernel<4, TAB, PW>), grid, dim3(256), 0, st, g, src, reinterpret_cast<const uint4*>(wp), out, slab, slab_stride);
 }
 
-// the pointwise fast path (conv_b16_kernel<.., PW>): 1x1x1, stride 1, no padding, frames of a multiple of 8 positions, 16-byte
-// aligned source
+// the octet-gather path (conv_b16_kernel<.., PW>): stride 1, channel counts multiples of 16, 16-byte aligned source, and either
+// 1x1x1 without padding on frames of a multiple of 8 positions (positions are then one linear run per channel), or taps whose
+// column offsets are -1 / 0 / +1 on rows that are multiples of 8 positions in BOTH the source (ws) and the enumerated tensor (wq)
 static bool b16_pointwise(const cstp_conv_desc* d, const void* src) {
   return d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
          ((d->d * d->h * d->w) % 8) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (d->c % 16) == 0 && (d->k % 16) == 0;
+}
+static bool b16_octets(const cstp_conv_desc* d, const void* src, int ws, int wq) {
+  if (b16_pointwise(d, src)) return true;
+  return d->st == 1 && d->sh == 1 && d->sw == 1 && d->kw <= 3 && d->pw <= 1 && d->kw - 1 - d->pw <= 1 &&
+         d->kt * d->kh * d->kw <= B16_MAXTAPS && (ws % 8) == 0 && (wq % 8) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+         (d->c % 16) == 0 && (d->k % 16) == 0;
 }
 
 static float* b16_slabs(void* ws, const cstp_conv_desc* d, const B16Geom& q) {
@@ -1178,7 +1219,7 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
           g.off[i][0] = (short)(a - d->pt); g.off[i][1] = (short)(b - d->ph); g.off[i][2] = (short)(c - d->pw); g.off[i][3] = (short)i;
         }
     if (pw) { g.wf32 = 1; b16_launch_conv<false, true>(st, g, d->k, x, w, y, slab, out_elems); }
-    else if (b16_pointwise(d, x)) b16_launch_conv<false, true>(st, g, d->k, x, wp, y, slab, out_elems);
+    else if (b16_octets(d, x, d->w, q.Wo)) b16_launch_conv<false, true>(st, g, d->k, x, wp, y, slab, out_elems);
     else b16_launch_conv<false>(st, g, d->k, x, wp, y, slab, out_elems);
   }
   CSTP_LAUNCH_CHECK();
@@ -1234,7 +1275,7 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
             }
         g.ntaps = i;
         g.ksplit = ksplit;
-        if (b16_pointwise(d, dy)) b16_launch_conv<false, true>(st, g, d->c, dy, wp, dx, slab, out_elems);
+        if (b16_octets(d, dy, q.Wo, d->w)) b16_launch_conv<false, true>(st, g, d->c, dy, wp, dx, slab, out_elems);
         else b16_launch_conv<false>(st, g, d->c, dy, wp, dx, slab, out_elems);
         CSTP_LAUNCH_CHECK();
       }

@@ -73,6 +73,11 @@ CONVS = [
     ((3, 48, 2, 6, 4), 80, (1, 1, 1), (1, 1, 1), (0, 0, 0)),          # pointwise path: ragged position tile, half K-tile, ragged rows
     ((8, 1024, 1, 4, 4), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # pointwise path with split-K (one position tile, 32 K-tiles)
     ((2, 64, 1, 7, 7), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),          # 1x1x1 on 7x7 frames (49 positions): NOT the pointwise path
+    ((2, 64, 3, 8, 16), 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # octet gathers with +-1 column taps: rows of 16, all 27 taps
+    ((2, 32, 2, 8, 8), 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),          # ... rows of exactly one octet (both edges in every octet)
+    ((2, 32, 4, 4, 8), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0)),          # ... temporal taps only (no column shift)
+    ((1, 48, 2, 4, 8), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),          # ... 48 channels: the second 32-channel block is half empty
+    ((2, 32, 3, 6, 8), 32, (3, 3, 3), (1, 1, 1), (0, 1, 1)),          # ... no temporal padding: the output has fewer frames than the source
 ]
 
 
