@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Host-side cost of one 3D-ResNet-50 pre-training step at BASELINE configs[4]'s per-GPU share: time to ENQUEUE a step vs time until
+the GPU has drained it, then a cProfile of five steps (where the Python time goes).
+
+    python tools/prof_host_r3d.py bf16|fp32
+"""
 import argparse, cProfile, pstats, sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from cstp_amd.optim import FlatSGD
