@@ -29,4 +29,6 @@ print("igemm_k2p: %d MFMA, %d transposing LDS reads, scratch instructions: %d, r
 bad += sp + (1 if wf > 12 else 0)
 sys.exit(1 if bad else 0)
 PY
+# every ds_read_b128 of the patch kernels is consumed behind an lgkmcnt wait that covers it (hand-counted waits: round-2 ADVICE)
+python3 tools/check_lds_waits.py $tmp/igemm.s
 rm -rf $tmp
