@@ -5,5 +5,5 @@ set -e
 name=$1; shift
 mkdir -p build_var
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -Iinclude -Icstp_amd/csrc "$@" -o build_var/$name.so \
-  cstp_amd/csrc/igemm.hip cstp_amd/csrc/bn.hip cstp_amd/csrc/misc.hip cstp_amd/csrc/clip.hip
+  cstp_amd/csrc/igemm.hip cstp_amd/csrc/bn.hip cstp_amd/csrc/misc.hip cstp_amd/csrc/clip.hip cstp_amd/csrc/b16.hip
 echo built build_var/$name.so
