@@ -29,6 +29,9 @@
 #ifndef KP_RING6
 #define KP_RING6 0    // 1: six-slot weight ring at 64 rows (measured neutral: 58.19 vs 58.11 ms/step -- the weight DMA is not what the short K-tiles wait for)
 #endif
+#ifndef KP_EPI_PERM
+#define KP_EPI_PERM 1  // epilogue: lanes re-ordered (ds_bpermute) so that the four lanes of a channel are neighbours: a 16-lane
+#endif                 // group of a store then writes 4 runs of 64 bytes instead of 16 pieces of 16 bytes (one per channel row)
 #ifndef KP_DIAG
 #define KP_DIAG 0     // timing-only diagnostic builds (wrong results): bit 0 = no patch staging after the prologue, bit 1 = no weight
 #endif                // DMA after the prologue, bit 2 = no products, bit 3 = no output stores
@@ -608,14 +611,20 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     const int sp_lo = h_lo * W + w_lo;
     const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;     // uniform
     if (vec_ok) {
+      // The accumulator tile has lane = 16 * (position quad q) + (channel fr): stored as it is, the 16 lanes of one pass of a
+      // 16-byte store hit 16 different channel rows.  KP_EPI_PERM: the values travel to lane 4 * fr + q first (ds_bpermute,
+      // no memory), so that a pass writes four runs of 64 contiguous bytes; addresses follow the NEW lane's (channel, quad).
+      const int sq = KP_EPI_PERM ? (lane & 3) : q;                    // position quad / channel whose values I STORE
+      const int sfr = KP_EPI_PERM ? (lane >> 2) : fr;
+      const int perm_src = (16 * (lane & 3) + (lane >> 2)) * 4;        // byte index of the lane whose values I receive
       size_t obase[KP_NTW];
       bool nok[KP_NTW];
       {
-        Cur c = {sp_lo + wn * (KP_NTW * 16) + 4 * q, d_lo, nb_lo};
+        Cur c = {sp_lo + wn * (KP_NTW * 16) + 4 * sq, d_lo, nb_lo};
 #pragma unroll
         for (int j = 0; j < KP_NTW; ++j) {
           norm(c);
-          nok[j] = pos0 + (wn * KP_NTW + j) * 16 + 4 * q < P;
+          nok[j] = pos0 + (wn * KP_NTW + j) * 16 + 4 * sq < P;
           obase[j] = offs(c);
           c.sp += 16;
         }
@@ -625,7 +634,8 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         const int mrow = (i < NI ? (mt0 + i) : (MT - 1)) * 16 + fr;
         const float sc = inva[mrow] * invb;
         const int m = mblk * BM + mrow;
-        float* orow = out + (size_t)m * chs;
+        const int ms = mblk * BM + (i < NI ? (mt0 + i) : (MT - 1)) * 16 + sfr;      // the channel I store
+        float* orow = out + (size_t)ms * chs;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         float vmin = __builtin_inff(), vmax = -__builtin_inff();      // STATS: smallest / largest accumulator of my channel
         float pv = 0.f;                                  // STATS: the pivot in accumulator units (y = v * sc)
@@ -634,9 +644,21 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
           const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
           if ((KP_DIAG & 8) && v[0] != 12345.f) continue;
-          if (nok[j] && m < g.M) {
+          f32x4 vs = v * sc;
+#if KP_EPI_PERM
+          {   // (the components through a plain struct: ext_vector component reads have miscompiled to component 0 here, see DESIGN)
+            struct F4 { float a, b, c, d; };
+            const F4 t4 = __builtin_bit_cast(F4, vs);
+            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.a)));
+            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.b)));
+            const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.c)));
+            const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.d)));
+            vs = f32x4{p0, p1, p2, p3};
+          }
+#endif
+          if (nok[j] && ms < g.M) {
             f32x4* dst = reinterpret_cast<f32x4*>(orow + obase[j]);
-            *dst = g.acc ? *dst + v * sc : v * sc;
+            *dst = g.acc ? *dst + vs : vs;
           }
           if constexpr (STATS) {                           // (every position of every tile is valid: host condition)
             const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv;

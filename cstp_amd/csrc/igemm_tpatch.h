@@ -429,10 +429,13 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // ---- epilogue (igemm_k1p's: transposed tile, one 16-byte store per lane and column tile).  A lane's four positions
     // p0 .. p0 + 3 are columns j0 .. j0 + 3 of frame d0 + p0 / 28 (28 is a multiple of four: never across frames).
     const int st_grp = STATS ? nb / g.gclips : 0;
+    // (KP_EPI_PERM, as in igemm_k1p: the values travel to lane 4 * channel + quad before they are stored)
+    const int sq = KP_EPI_PERM ? (lane & 3) : q, sfr = KP_EPI_PERM ? (lane >> 2) : fr;
+    const int perm_src = (16 * (lane & 3) + (lane >> 2)) * 4;
     size_t obase[KP_NTW];
 #pragma unroll
     for (int j = 0; j < KP_NTW; ++j) {
-      const int p0 = (wn * KP_NTW + j) * 16 + 4 * q;
+      const int p0 = (wn * KP_NTW + j) * 16 + 4 * sq;
       const int dl = p0 / KT_WT, jj = p0 - dl * KT_WT;
       obase[j] = ((size_t)nb * g.M * g.D + d0 + dl) * HW + hw0 + jj;
     }
@@ -441,7 +444,8 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       const int mrow = (i < NI ? (mt0 + i) : (MT - 1)) * 16 + fr;
       const float sc = inva[mrow] * invb;
       const int m = mblk * BM + mrow;
-      float* orow = out + (size_t)m * chs;
+      const int ms = mblk * BM + (i < NI ? (mt0 + i) : (MT - 1)) * 16 + sfr;
+      float* orow = out + (size_t)ms * chs;
       f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
       float vmin = __builtin_inff(), vmax = -__builtin_inff();
       float pv = 0.f;
@@ -449,9 +453,21 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 #pragma unroll
       for (int j = (i < NI ? 0 : XJ0); j < (i < NI ? KP_NTW : XJ0 + XJN); ++j) {
         const f32x4 v = i < NI ? acc[i < NI ? i : 0][j] : accx[i < NI ? 0 : j - XJ0];
-        if (m < g.M) {
+        f32x4 vs = v * sc;
+#if KP_EPI_PERM
+        {   // (the components through a plain struct: ext_vector component reads have miscompiled to component 0 here, see DESIGN)
+            struct F4 { float a, b, c, d; };
+            const F4 t4 = __builtin_bit_cast(F4, vs);
+          const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.a)));
+          const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.b)));
+          const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.c)));
+          const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src, __builtin_bit_cast(int, t4.d)));
+          vs = f32x4{p0, p1, p2, p3};
+        }
+#endif
+        if (ms < g.M) {
           f32x4* dst = reinterpret_cast<f32x4*>(orow + obase[j]);
-          *dst = g.acc ? *dst + v * sc : v * sc;
+          *dst = g.acc ? *dst + vs : vs;
         }
         if constexpr (STATS) {
           const f32x4 dv = v - pv; s1 += dv; s2 += dv * dv;
