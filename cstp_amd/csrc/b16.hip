@@ -396,7 +396,26 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int P0 = n0 + wave * 32 + a * 16 + 4 * (lane >> 4);
-    if (g.contig) {
+    if (g.contig && sl == nullptr) {
+      // bf16 results, 8 bytes per lane.  As the accumulator tile stands, lane = 16 * (position quad) + channel: the 16 lanes of a
+      // store pass would write 16 pieces of 8 bytes, one per channel row.  The packed values travel to lane 4 * channel + quad
+      // first (two ds_bpermute per tile), so that a pass writes four runs of 32 contiguous bytes (igemm_k1p's KP_EPI_PERM).
+      const int sq = lane & 3, sfr = lane >> 2;
+      const int perm_src = (16 * sq + sfr) * 4;
+      const int Ps = n0 + wave * 32 + a * 16 + 4 * sq;
+      const bool pok = Ps < npos;
+      const int nbo = (pok ? Ps : 0) / npq, pos = (pok ? Ps : 0) - nbo * npq;
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        struct F4 { float a, b, c, d; };
+        const F4 t4 = __builtin_bit_cast(F4, acc[a][b]);      // (plain struct: ext_vector component reads have miscompiled, DESIGN)
+        const int lo = __builtin_amdgcn_ds_bpermute(perm_src, (int)pack_bf2(t4.a, t4.b));
+        const int hi = __builtin_amdgcn_ds_bpermute(perm_src, (int)pack_bf2(t4.c, t4.d));
+        const int m = m0 + b * 16 + sfr;
+        if (pok && m < g.M)
+          *reinterpret_cast<uint2*>(out + ((size_t)nbo * g.M + m) * DHWo + pos) = make_uint2((unsigned)lo, (unsigned)hi);
+      }
+    } else if (g.contig) {
       if (P0 >= npos) continue;
       const int nbo = P0 / npq, pos = P0 - nbo * npq;
 #pragma unroll
@@ -404,9 +423,7 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
         const int m = m0 + b * 16 + (lane & 15);
         if (m >= g.M) continue;
         const f32x4 v = acc[a][b];
-        const size_t o = ((size_t)nbo * g.M + m) * DHWo + pos;
-        if (sl != nullptr) *reinterpret_cast<f32x4*>(sl + o) = v;
-        else *reinterpret_cast<uint2*>(out + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        *reinterpret_cast<f32x4*>(sl + ((size_t)nbo * g.M + m) * DHWo + pos) = v;
       }
     } else {
       size_t ooff[4];
