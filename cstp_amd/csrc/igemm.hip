@@ -1149,15 +1149,16 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
 // BatchNorm partial sums as a by-product of a forward patch launch (igemm_k1p<MT, true>): possible when every 224-position tile
 // is full and lies inside one BN group, the output allows 16-byte stores, and a block meets one row block only
 struct K1pStats { double* part; int groups; const float* pivot; unsigned* zcell; };
-static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out);
+static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out, int groups = 1);
 static int k1p_stats_nsplit(const Tile& tl, const cstp_conv_desc& d, int groups) {
   if (tl.sp != 2 || groups < 1 || groups > 2 || d.n % groups != 0) return 0;
   const long gpos = (long)(d.n / groups) * d.d * d.h * d.w;
   if (gpos % KP_NPOS != 0 || ((d.h * d.w) & 3) != 0) return 0;
   int ntiles, nmblk;
-  const int slots = k1p_grid_slots(d, d.k, tl.mt, &ntiles, &nmblk);
-  if (slots % nmblk != 0) return 0;
-  return 8 * slots / nmblk;
+  const int slots = k1p_grid_slots(d, d.k, tl.mt, &ntiles, &nmblk, groups);
+  // the slots of an XCD are dealt to the groups alternately; every block meets one (group, row block) only
+  if (slots == 0 || slots % (groups * nmblk) != 0) return 0;
+  return 8 * (slots / groups) / nmblk;
 }
 
 // the temporal layers: igemm_k1t (same packed-weight format with three taps, same grid, same partial-sum table)
@@ -1183,7 +1184,7 @@ static void run_k1t(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
-  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr);
+  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr, st ? st->groups : 1);
   dim3 grid((unsigned)(8 * slots), 1, 1);
   double* part = st ? st->part : nullptr;
   const float* pivot = st ? st->pivot : nullptr;
@@ -1216,6 +1217,13 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   g.H = d.h; g.W = d.w; g.D = d.d; g.NF = d.n * d.d;
   g.M = dgrad ? d.c : d.k;
   g.rows_lds = patch_rows_needed(g.NF, g.H, g.W);
+  {
+    // staging by 16-byte loads (igemm_patch.h, QUAD): whole column quads, whole 8-channel groups, aligned lines, three rounds
+    static const bool quad_on = [] { const char* e = getenv("CSTP_K1P_QUAD"); return e == nullptr || atoi(e) != 0; }();
+    const int lines = g.rows_lds / (g.W + 2);
+    g.quad = quad_on && (g.W & 3) == 0 && (g.Cs & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+             lines * (g.W / 4) * 2 <= 192 && g.rows_lds + 32 <= KP_ROWS ? 1 : 0;
+  }
   const int bm = 16 * tl.mt, nmblk = cdiv(g.M, bm);
   const long P = (long)g.NF * g.H * g.W;
   const int ntiles = (int)((P + KP_NPOS - 1) / KP_NPOS);
@@ -1226,7 +1234,7 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
   if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
-  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr);
+  const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr, st ? st->groups : 1);
   dim3 grid((unsigned)(8 * slots), 1, 1);
   double* part = st ? st->part : nullptr;
   const float* pivot = st ? st->pivot : nullptr;
@@ -1241,7 +1249,9 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
 }
 
 // persistent blocks, one per CU (the LDS image fills it): 256 of them, or fewer when there is less work; returns slots per XCD
-static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out) {
+// (groups > 1: a BatchNorm-statistics launch over that many view groups -- the slots of an XCD are dealt to the groups in turn,
+//  so their number is a multiple of groups * row blocks; 0 = no such grid)
+static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_out, int* nmblk_out, int groups) {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1254,6 +1264,11 @@ static int k1p_grid_slots(const cstp_conv_desc& d, int M, int mt, int* ntiles_ou
   const int ntiles = (int)((P + KP_NPOS - 1) / KP_NPOS), nmblk = cdiv(M, 16 * mt);
   if (ntiles_out) *ntiles_out = ntiles;
   if (nmblk_out) *nmblk_out = nmblk;
+  if (groups > 1) {
+    const int per_xcd_g = cdiv(cdiv(ntiles, groups), 8) * nmblk * groups;
+    const int slots_g = per_xcd_g < n_cu / 8 ? per_xcd_g : n_cu / 8;
+    return slots_g / (groups * nmblk) * (groups * nmblk);
+  }
   const int per_xcd = cdiv(ntiles, 8) * nmblk;        // items of the busiest XCD
   const int slots = per_xcd < n_cu / 8 ? per_xcd : n_cu / 8;
   return slots > 0 ? slots : 1;

@@ -32,6 +32,9 @@
 #ifndef KP_EPI_PERM
 #define KP_EPI_PERM 1  // epilogue: lanes re-ordered (ds_bpermute) so that the four lanes of a channel are neighbours: a 16-lane
 #endif                 // group of a store then writes 4 runs of 64 bytes instead of 16 pieces of 16 bytes (one per channel row)
+#ifndef KP_XSPLIT
+#define KP_XSPLIT 4   // odd MT: column tiles of the shared last row tile that the FIRST row-wave pair takes (the second takes the rest)
+#endif
 #ifndef KP_DIAG
 #define KP_DIAG 0     // timing-only diagnostic builds (wrong results): bit 0 = no patch staging after the prologue, bit 1 = no weight
 #endif                // DMA after the prologue, bit 2 = no products, bit 3 = no output stores
@@ -56,9 +59,10 @@ struct PGeom {
   int H, W, D, NF;  // frame size, frames per clip, frames in total (Nb * D)
   int M;            // valid output rows (channels of `out`)
   int rows_lds;     // LDS rows a tile can touch (<= KP_ROWS)
-  int gpos;         // STATS: output positions per BatchNorm group (a multiple of KP_NPOS: no tile straddles two groups)
+  int gpos;         // STATS: output positions per BatchNorm group (a multiple of KP_NPOS: a group is a whole number of tiles)
   int groups;       // STATS: BatchNorm groups (<= 2)
   int acc = 0;      // out += instead of out = (the caller's gradient accumulation; data gradient)
+  int quad = 0;     // staging by 16-byte loads (four columns of one channel per lane): W % 4 == 0, Cs % 8 == 0, 16-byte-aligned src
 };
 
 // packed weights for igemm_k1p: wpk[mblk][kt = cb * 9 + tap][row (16*MT)][physical chunk (8)][8 f16], row m scaled by a power of
@@ -147,11 +151,12 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   // lasts ~0.3 us, and a weight piece requested two K-tiles ahead (0.6 us) is not back from L2 when its K-tile starts: the
   // DMA waves' wait, and behind it the barrier, set the K-tile time.  Five K-tiles of lead cost 24 KB.
   constexpr int RING = KP_RING6 && MT == 4 ? 6 : 3;
-  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
+  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? BM + BM / 2 : 0)];
   uint4* const ring = smem;
   uint4* const patch = smem + RING * A_U4;
   float* const inva_s = reinterpret_cast<float*>(smem + RING * A_U4 + 2 * P_U4);      // [2][BM], by item parity
-  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
+  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [BM][2] sums of the block's group
+  unsigned* const mm_s = reinterpret_cast<unsigned*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + BM);   // STATS: [BM][2] range keys
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -160,49 +165,53 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   // owns a contiguous chunk of position tiles; its blocks (slots) walk that chunk's items round-robin, so at any moment the
   // blocks of one XCD work on neighbouring tiles and on the row blocks of the same tile (shared patch and halo rows in L2).
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int chunk = (ntiles + 7) >> 3;
-  int tiles_x = ntiles - xcd * chunk;
+  // STATS with two BatchNorm groups: the slots of an XCD are dealt to the groups alternately and a block walks the tiles of ITS
+  // group only (host: nslots is a multiple of groups * nmblk, a group is a whole number of tiles), so the block's sums and its
+  // range live in one group's worth of LDS and no tile sequence ever crosses a group boundary.
+  const int ngrp = STATS ? g.groups : 1;
+  const int bgrp = slot % ngrp, gslot = slot / ngrp, gnslots = nslots / ngrp;
+  const int gtiles = ntiles / ngrp;
+  const int chunk = (gtiles + 7) >> 3;
+  int tiles_x = gtiles - xcd * chunk;
   tiles_x = tiles_x < 0 ? 0 : (tiles_x < chunk ? tiles_x : chunk);
-  const int cnt_x = tiles_x * nmblk;                 // items of this XCD
-  const int nitems = slot < cnt_x ? (cnt_x - slot + nslots - 1) / nslots : 0;
-  // STATS: this block's slot in the partial-sum table (the host makes nslots a multiple of nmblk, so a block meets one row block only)
-  const int st_mblk = slot % nmblk, st_nsplit = (gridDim.x >> 3) * 8 / nmblk, st_j = xcd * (nslots / nmblk) + slot / nmblk;
+  const int cnt_x = tiles_x * nmblk;                 // items of this XCD (in my group)
+  const int nitems = gslot < cnt_x ? (cnt_x - gslot + gnslots - 1) / gnslots : 0;
+  // STATS: this block's slot in the partial-sum table (gnslots is a multiple of nmblk, so a block meets one row block only)
+  const int st_mblk = gslot % nmblk, st_nsplit = gnslots * 8 / nmblk, st_j = xcd * (gnslots / nmblk) + gslot / nmblk;
+  // the range table sits behind the partial sums and the pivots: mm[((ch * groups + grp) * nsplit + j) * 2 + {min, max}]
+  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
   auto write_part = [&](bool zeros) __attribute__((always_inline)) {
-    for (int e = threadIdx.x; e < g.groups * BM * 2; e += 256) {
-      const int k = e & 1, row = (e >> 1) % BM, grp = (e >> 1) / BM;
+    for (int e = threadIdx.x; e < BM * 2; e += 256) {
+      const int k = e & 1, row = e >> 1;
       const int ch = st_mblk * BM + row;
-      if (ch < g.M) part[(((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2 + k] = zeros ? 0.0 : stat_s[(grp * BM + row) * 2 + k];
+      if (ch < g.M) {
+        const size_t at = (((size_t)ch * g.groups + bgrp) * st_nsplit + st_j) * 2 + k;
+        part[at] = zeros ? 0.0 : stat_s[row * 2 + k];
+        mmk[at] = zeros ? (k == 0 ? 0xffffffffu : 0u) : mm_s[row * 2 + k];
+      }
     }
     // the pivot the sums are taken around rides behind the partials (one writer per row block), so that the fold works with
     // exactly the value this launch used
-    if (st_j == 0) {
+    if (st_j == 0 && bgrp == 0) {
       for (int row = threadIdx.x; row < BM; row += 256) {
         const int ch = st_mblk * BM + row;
         if (ch < g.M) part[(size_t)g.M * g.groups * st_nsplit * 2 + ch] = pivot != nullptr ? (double)pivot[ch] : 0.0;
       }
     }
   };
-  // STATS: my slots of the minimum / maximum table start neutral; the consumers' atomics (many barriers later) shrink / grow them
-  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
   if constexpr (STATS) {
-    for (int e = threadIdx.x; e < g.groups * BM; e += 512) {
-      const int row = e % BM, grp = e / BM, ch = st_mblk * BM + row;
-      if (ch < g.M)
-        *reinterpret_cast<uint2*>(mmk + (((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2) = make_uint2(0xffffffffu, 0u);
-    }
     // the cell the BatchNorm finalize takes the consumer's operand maximum into (atomicMax): zeroed here, a launch earlier
     if (blockIdx.x == 0 && threadIdx.x == 0 && zcell != nullptr) *zcell = 0;
-    __threadfence();
   }
   if (nitems == 0) {
     if constexpr (STATS) { if (threadIdx.x < 256) write_part(true); }
     return;
   }
   auto item_of = [&](int it, int& tile, int& mblk) __attribute__((always_inline)) {
-    const int idx = slot + it * nslots;
+    const int idx = gslot + it * gnslots;
     const int t_in = idx / nmblk;
     mblk = idx - t_in * nmblk;
-    tile = xcd * chunk + t_in;
+    tile = bgrp * gtiles + xcd * chunk + t_in;
   };
 
   const int H = g.H, W = g.W, HW = H * W, PITCH = W + 2;
@@ -266,6 +275,9 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // rounds in flight with counted waits (igemm_split.h explains what a conditional load costs).
     constexpr int NR = (KP_ROWS + 63) / 64;            // 7
     static_assert(NR <= 7, "rounds must fit the nine taps of a channel block");
+#ifdef KP_SPRIO
+    __builtin_amdgcn_s_setprio(KP_SPRIO);
+#endif
     const int half = wave - 6;
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, (unsigned)((size_t)(g.NF / g.D) * g.Cs * chs * 4));
@@ -334,6 +346,134 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         row[(5 + 2 * half) ^ x7] = pl[1];
       }
     };
+
+    if (g.quad) {
+      // ---- QUAD staging (round 4).  The dword rounds above keep 16 x 4-byte loads per lane and round in flight and a wave can have
+      // 63 vector-memory operations outstanding in all (vmcnt is six bits): the staging stream was latency-bound by its own
+      // instruction count, and its 112 loads + address work per channel block came straight out of the issue slots of the SIMDs it
+      // shares with two consumer waves (diagnostic builds, S1 forward: 0.74 ms with the staging, 0.56 without; the staging alone
+      // 0.18: fully additive).  Here a task is (image line, four consecutive columns, 8-channel group): eight 16-byte loads (one
+      // per channel: 64 consecutive lanes cover up to 1 KiB of one channel's contiguous lines) give a lane the two 16-byte
+      // chunks (hi, lo) of FOUR LDS rows.  lines * (W / 4) * 2 tasks per wave (wave 6: channel groups 0, 1; wave 7: 2, 3) = 168 at
+      // 56 x 56 and 28 x 28 = three rounds: 24 loads per lane and channel block instead of 112.  The halo COLUMNS (-1 and W) of
+      // every line are the zero padding itself: their LDS rows are zeroed once.
+      constexpr int QR = 3;
+      const int QW = W >> 2, nlines = g.rows_lds / PITCH;
+      const int ntask = nlines * QW * 2;
+      for (int e = lane + 64 * half; e < 2 * nlines * 2 * 8; e += 128) {     // (buffer, line, left / right halo row, chunk)
+        const int c8 = e & 7, side = (e >> 3) & 1, rest = e >> 4, line = rest % nlines, buf = rest / nlines;
+        patch[buf * P_U4 + (line * PITCH + (side ? W + 1 : 0)) * 8 + c8] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      int q_row0[QR], q_line[QR], q_col[QR], q_gch[QR];
+      bool q_ok[QR];
+#pragma unroll
+      for (int r = 0; r < QR; ++r) {
+        const int tk = lane + 64 * r;
+        q_ok[r] = tk < ntask;
+        const int tq = q_ok[r] ? tk : 0;
+        const int qi = tq >> 1;
+        q_gch[r] = 2 * half + (tq & 1);                  // my 8-channel group of the 32-channel block
+        q_line[r] = qi / QW;
+        q_col[r] = 4 * (qi - q_line[r] * QW);
+        // (lanes past the last task stage zeros into four spare rows behind the tile's image -- host: rows_lds + 32 <= KP_ROWS --
+        //  so that no store is conditional)
+        q_row0[r] = q_ok[r] ? q_line[r] * PITCH + 1 + q_col[r] : g.rows_lds + 4 * (lane & 7);
+      }
+      const unsigned ch4q = (unsigned)(chs * 4);
+      auto quad_offsets = [&](int tile, unsigned (&voff)[QR]) __attribute__((always_inline)) {
+        const int pos0 = tile * KP_NPOS;
+        const int pos_last = (pos0 + KP_NPOS - 1 < P ? pos0 + KP_NPOS - 1 : P - 1);
+        const int v_lo = pos0 / W, v_last = pos_last / W;
+        const int f_lo = v_lo / H;
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+          // line -> (frame, h): frame k of the tile owns (its image rows inside the tile) + 2 lines, halo above and below
+          int rem = q_line[r], f = f_lo, v0 = v_lo, h = -1;
+          bool ok = false;
+#pragma unroll 1
+          for (int i = 0; i < 8; ++i) {
+            int fend = (f + 1) * H - 1;
+            fend = fend < v_last ? fend : v_last;
+            const int cnt = fend - v0 + 3;
+            if (rem < cnt) { h = v0 - 1 + rem - f * H; ok = true; break; }
+            rem -= cnt;
+            ++f;
+            v0 = f * H;
+            if (v0 > v_last) break;
+          }
+          ok = ok && q_ok[r] && h >= 0 && h < H && f < g.NF;
+          const int nb = f / g.D, d = f - nb * g.D;
+          voff[r] = ok ? (unsigned)(((size_t)nb * g.Cs * chs + (size_t)d * HW + h * W + q_col[r]) * 4) + (unsigned)(q_gch[r] * 8) * ch4q
+                       : OOB;
+        }
+      };
+      struct QRound { u32x4 v[8]; };
+      auto q_load = [&](int r, unsigned vo, int cb, QRound& rd) __attribute__((always_inline)) {
+        // (channel groups past the tensor's last channel: zeros against zero weights)
+        const unsigned v = (cb * 32 + q_gch[r] * 8 < g.Cs) ? vo : OOB;
+        const unsigned so = (unsigned)(cb * 32) * ch4q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) buf_load_x4(rd.v[e], v, rs_src, so + (unsigned)e * ch4q);
+      };
+      auto q_store = [&](int buf, int r, const QRound& rd) __attribute__((always_inline)) {
+        // (the components through a float vector: indexing rd.v[e][i] directly has made hipcc read component 0 for every i)
+        f32x4 vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[e] = __builtin_bit_cast(f32x4, rd.v[e]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                   // my four LDS rows
+          uint4 ph, pl;
+          unsigned hh, ll;
+          split2h(vf[0][i], vf[1][i], sb, hh, ll); ph.x = hh; pl.x = ll;
+          split2h(vf[2][i], vf[3][i], sb, hh, ll); ph.y = hh; pl.y = ll;
+          split2h(vf[4][i], vf[5][i], sb, hh, ll); ph.z = hh; pl.z = ll;
+          split2h(vf[6][i], vf[7][i], sb, hh, ll); ph.w = hh; pl.w = ll;
+          const int row = q_row0[r] + i;
+          uint4* prow = patch + buf * P_U4 + row * 8;
+          const int x7 = row & 7;
+          prow[q_gch[r] ^ x7] = ph;
+          prow[(4 + q_gch[r]) ^ x7] = pl;
+        }
+      };
+      unsigned qv_cur[QR], qv_nxt[QR];
+      int tile, mb_unused;
+      item_of(0, tile, mb_unused);
+      quad_offsets(tile, qv_cur);
+#pragma unroll
+      for (int r = 0; r < QR; ++r) qv_nxt[r] = OOB;
+      QRound rq[QR];
+#pragma unroll
+      for (int r = 0; r < QR; ++r) q_load(r, qv_cur[r], 0, rq[r]);
+#pragma unroll
+      for (int r = 0; r < QR; ++r) q_store(0, r, rq[r]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int pb = 0;
+      for (int it = 0; it < nitems; ++it) {
+        const bool next_item = it + 1 < nitems;
+        for (int cb = 0; cb < g.ncb; ++cb) {
+          const bool last_cb = cb + 1 == g.ncb;
+          const bool stage = (!last_cb || next_item) && !(KP_DIAG & 1);
+          if (last_cb && next_item) {
+            item_of(it + 1, tile, mb_unused);
+            quad_offsets(tile, qv_nxt);
+          }
+          const int ncb_ = last_cb ? 0 : cb + 1;
+          // round t is LOADED at tap t (t = 0, 1, 2) and STORED four taps later
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            if (tap >= 4 && tap - 4 < QR) q_store(pb ^ 1, tap - 4, rq[tap - 4]);
+            if (tap < QR) q_load(tap, stage ? (last_cb ? qv_nxt[tap] : qv_cur[tap]) : OOB, ncb_, rq[tap]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          pb ^= 1;
+        }
+#pragma unroll
+        for (int r = 0; r < QR; ++r) qv_cur[r] = qv_nxt[r];
+      }
+      return;
+    }
 
     unsigned voff_cur[NR], voff_nxt[NR];
     int tile, mb_unused;
@@ -406,7 +546,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   const int q = lane >> 4;
 
   if constexpr (STATS) {
-    for (int e = t; e < 2 * BM * 2; e += 256) stat_s[e] = 0.0;       // (consumer threads are t < 256; read many barriers later)
+    for (int e = t; e < BM * 2; e += 256) { stat_s[e] = 0.0; mm_s[e] = (e & 1) ? 0u : 0xffffffffu; }   // (consumer threads are t < 256; read many barriers later)
   }
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
 #ifndef KP_PRIO
@@ -422,6 +562,9 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   int pb = 0, slot3 = 0;
   for (int it = 0; it < nitems; ++it) {
     int tile, mblk;
+#if KP_DIAG & 16
+    const unsigned long long t_item0 = KP_T();
+#endif
     item_of(it, tile, mblk);
     const int pos0 = tile * KP_NPOS;
     // (pos0 is uniform: these three divisions are the item's only ones -- every per-lane position below is reached from
@@ -443,6 +586,15 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     for (int j = 0; j < (XJN > 0 ? XJN : 1); ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) accx[j][r] = 0.f;
+#if KP_DIAG & 128
+    // timing-only diagnostic (wrong results): the whole row tiles' products as v_mfma_f32_32x32x16_f16 -- the same multiply-add
+    // count in half the instructions, each holding the SIMD's issue port 8 of 32 cycles instead of 8 of 16
+    f32x16 accq[KP_NTW];
+#pragma unroll
+    for (int j = 0; j < KP_NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accq[j][r] = 0.f;
+#endif
 
     // LDS row of my column in each of my 7 column tiles, one line above / one column left of it; a tap adds dh * PITCH + dw
     int base[KP_NTW];
@@ -548,6 +700,23 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         // (j is a constant after unrolling: this test folds)
         const bool xj = XJN > 0 && j >= XJ0 && j < XJ0 + XJN;
         const int jx = xj ? j - XJ0 : 0;
+#if KP_DIAG & 128
+        if constexpr (NI == 4) {
+#pragma unroll
+          for (int i = 0; i < NI; i += 2) {
+            accq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhj, al[i], accq[j], 0, 0, 0);
+            accq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blj, ah[i + 1], accq[j], 0, 0, 0);
+            accq[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhj, ah[i], accq[j], 0, 0, 0);
+          }
+          if (xj) {
+            accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[NI + XA - 1], accx[jx], 0, 0, 0);
+            accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
+            accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, ah[NI + XA - 1], accx[jx], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[i], acc[i][j], 0, 0, 0);
         if (xj) accx[jx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhj, al[NI + XA - 1], accx[jx], 0, 0, 0);
@@ -586,6 +755,16 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     s_loop = t_loop1 - t_loop0;
 #endif
     // (pb has moved on to the buffer that holds the next item's first channel block)
+#if KP_DIAG & 128
+    if constexpr (NI == 4) {
+#pragma unroll
+      for (int j = 0; j < KP_NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = accq[j][4 * i + r];
+    }
+#endif
 
     // ---- epilogue.  The products are issued with the POSITIONS as the MFMA's row operand and the weight rows as its column
     // operand, so the accumulator tile is the transpose of the usual one: col = lane & 15 is an OUTPUT ROW (channel) and
@@ -600,7 +779,6 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     // Output offsets without divisions: the tile's first position is (frame f_lo, line h_lo, column w_lo); a lane's positions
     // are reached from there by stepping (frame-internal offset sp, frame of the clip d, clip nb).
     const int nb_lo = f_lo / g.D, d_lo = f_lo - nb_lo * g.D;      // uniform
-    const int st_grp = STATS ? pos0 / g.gpos : 0;                  // the BatchNorm group this tile belongs to (uniform)
     struct Cur { int sp, d, nb; };
     auto norm = [&](Cur& c) __attribute__((always_inline)) {
       while (c.sp >= HW) { c.sp -= HW; if (++c.d == g.D) { c.d = 0; ++c.nb; } }
@@ -672,17 +850,16 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
           a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
           a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
           if (q == 0 && m < g.M) {
-            double* dst = stat_s + (st_grp * BM + mrow) * 2;
+            double* dst = stat_s + mrow * 2;
             __hip_atomic_fetch_add(dst, (double)(a * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(dst + 1, (double)(b * sc) * (double)sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           // the range: sc > 0 and rounding is monotone, so min(v) * sc IS the smallest stored output
           vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 16, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 16, 64));
           vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 32, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 32, 64));
-          if (q == 0 && m < g.M) {
-            unsigned* mm = mmk + (((size_t)m * g.groups + st_grp) * st_nsplit + st_j) * 2;
-            atomicMin(mm, key_of_float(vmin * sc));
-            atomicMax(mm + 1, key_of_float(vmax * sc));
+          if (q == 0 && m < g.M) {       // (LDS atomics next to the sums; round 3 sent two device-scope atomics per lane-channel and ITEM)
+            __hip_atomic_fetch_min(mm_s + mrow * 2, key_of_float(vmin * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(mm_s + mrow * 2 + 1, key_of_float(vmax * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
@@ -722,6 +899,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     if (stamp && lane == 0) {
       kp_stamp[0] += s_loop; kp_stamp[1] += s_bar; kp_stamp[2] += s_a; kp_stamp[3] += KP_T() - t_loop1;
       kp_stamp[4] += (unsigned long long)nkt; kp_stamp[5] += 1; kp_stamp[6] += r_loop1 - r_loop0;
+      kp_stamp[7] += KP_T() - t_item0;              // the whole item: set-up + K loops + epilogue
     }
 #endif
   }
@@ -730,8 +908,8 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   if constexpr (MT % 2 == 0) {
     body(integral_constant<int, 0>{}, integral_constant<int, 0>{});
   } else {
-    if (wm == 0) body(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-    else body(integral_constant<int, 4>{}, integral_constant<int, KP_NTW - 4>{});
+    if (wm == 0) body(integral_constant<int, 0>{}, integral_constant<int, KP_XSPLIT>{});
+    else body(integral_constant<int, KP_XSPLIT>{}, integral_constant<int, KP_NTW - KP_XSPLIT>{});
   }
   if constexpr (STATS) {
     // the four consumer waves are the block's only live waves here (the others returned behind their last barrier)

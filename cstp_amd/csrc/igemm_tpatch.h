@@ -55,56 +55,59 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   constexpr int A_DMA = BM / 8;                      // 1 KiB LDS-DMA pieces per K-tile
   constexpr int P_U4 = KT_ROWS * 8;
   constexpr int RING = KP_RING6 && MT == 4 ? 6 : 3;   // weight ring: six K-tiles at 64 rows (igemm_k1p explains)
-  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? 2 * BM : 0)];
+  __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? BM + BM / 2 : 0)];
   __shared__ __attribute__((aligned(16))) float aff_a[AFF ? 2 * KT_AFFC : 4], aff_b[AFF ? 2 * KT_AFFC : 4];
   uint4* const ring = smem;
   uint4* const patch = smem + RING * A_U4;
   float* const inva_s = reinterpret_cast<float*>(smem + RING * A_U4 + 2 * P_U4);      // [2][BM], by item parity
-  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [2 groups][BM][2]
+  double* const stat_s = reinterpret_cast<double*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4));   // STATS: [BM][2] sums of the block's group
+  unsigned* const mm_s = reinterpret_cast<unsigned*>(smem + RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + BM);   // STATS: [BM][2] range keys
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
   // persistent blocks, work item = (position tile, row block), XCD-aware order: exactly igemm_k1p's
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int chunk = (ntiles + 7) >> 3;
-  int tiles_x = ntiles - xcd * chunk;
+  // STATS with two BatchNorm groups: slots dealt to the groups alternately, a block walks tiles of its group only (igemm_k1p)
+  const int ngrp = STATS ? g.groups : 1;
+  const int bgrp = slot % ngrp, gslot = slot / ngrp, gnslots = nslots / ngrp;
+  const int gtiles = ntiles / ngrp;
+  const int chunk = (gtiles + 7) >> 3;
+  int tiles_x = gtiles - xcd * chunk;
   tiles_x = tiles_x < 0 ? 0 : (tiles_x < chunk ? tiles_x : chunk);
   const int cnt_x = tiles_x * nmblk;
-  const int nitems = slot < cnt_x ? (cnt_x - slot + nslots - 1) / nslots : 0;
-  const int st_mblk = slot % nmblk, st_nsplit = (gridDim.x >> 3) * 8 / nmblk, st_j = xcd * (nslots / nmblk) + slot / nmblk;
+  const int nitems = gslot < cnt_x ? (cnt_x - gslot + gnslots - 1) / gnslots : 0;
+  const int st_mblk = gslot % nmblk, st_nsplit = gnslots * 8 / nmblk, st_j = xcd * (gnslots / nmblk) + gslot / nmblk;
+  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
   auto write_part = [&](bool zeros) __attribute__((always_inline)) {
-    for (int e = threadIdx.x; e < g.groups * BM * 2; e += 256) {
-      const int k = e & 1, row = (e >> 1) % BM, grp = (e >> 1) / BM;
+    for (int e = threadIdx.x; e < BM * 2; e += 256) {
+      const int k = e & 1, row = e >> 1;
       const int ch = st_mblk * BM + row;
-      if (ch < g.M) part[(((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2 + k] = zeros ? 0.0 : stat_s[(grp * BM + row) * 2 + k];
+      if (ch < g.M) {
+        const size_t at = (((size_t)ch * g.groups + bgrp) * st_nsplit + st_j) * 2 + k;
+        part[at] = zeros ? 0.0 : stat_s[row * 2 + k];
+        mmk[at] = zeros ? (k == 0 ? 0xffffffffu : 0u) : mm_s[row * 2 + k];
+      }
     }
-    if (st_j == 0) {
+    if (st_j == 0 && bgrp == 0) {
       for (int row = threadIdx.x; row < BM; row += 256) {
         const int ch = st_mblk * BM + row;
         if (ch < g.M) part[(size_t)g.M * g.groups * st_nsplit * 2 + ch] = pivot != nullptr ? (double)pivot[ch] : 0.0;
       }
     }
   };
-  unsigned* const mmk = STATS ? reinterpret_cast<unsigned*>(part + (size_t)g.M * g.groups * st_nsplit * 2 + g.M) : nullptr;
   if constexpr (STATS) {
-    for (int e = threadIdx.x; e < g.groups * BM; e += 512) {
-      const int row = e % BM, grp = e / BM, ch = st_mblk * BM + row;
-      if (ch < g.M)
-        *reinterpret_cast<uint2*>(mmk + (((size_t)ch * g.groups + grp) * st_nsplit + st_j) * 2) = make_uint2(0xffffffffu, 0u);
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && zcell != nullptr) *zcell = 0;
-    __threadfence();
   }
   if (nitems == 0) {
     if constexpr (STATS) { if (threadIdx.x < 256) write_part(true); }
     return;
   }
   auto item_of = [&](int it, int& tile, int& mblk) __attribute__((always_inline)) {
-    const int idx = slot + it * nslots;
+    const int idx = gslot + it * gnslots;
     const int t_in = idx / nmblk;
     mblk = idx - t_in * nmblk;
-    tile = xcd * chunk + t_in;
+    tile = bgrp * gtiles + xcd * chunk + t_in;
   };
   // tile -> (clip, first frame, first column); the column tiles of a frame row are neighbours in the order (shared cache lines)
   auto tile_at = [&](int tile, int& nb, int& d0, int& hw0) __attribute__((always_inline)) {
@@ -321,7 +324,7 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   const int q = lane >> 4;
 
   if constexpr (STATS) {
-    for (int e = t; e < 2 * BM * 2; e += 256) stat_s[e] = 0.0;
+    for (int e = t; e < BM * 2; e += 256) { stat_s[e] = 0.0; mm_s[e] = (e & 1) ? 0u : 0xffffffffu; }
   }
   __builtin_amdgcn_s_barrier();                        // the first item's prologue data is staged
   __builtin_amdgcn_s_setprio(2);
@@ -428,7 +431,6 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 
     // ---- epilogue (igemm_k1p's: transposed tile, one 16-byte store per lane and column tile).  A lane's four positions
     // p0 .. p0 + 3 are columns j0 .. j0 + 3 of frame d0 + p0 / 28 (28 is a multiple of four: never across frames).
-    const int st_grp = STATS ? nb / g.gclips : 0;
     // (KP_EPI_PERM, as in igemm_k1p: the values travel to lane 4 * channel + quad before they are stored)
     const int sq = KP_EPI_PERM ? (lane & 3) : q, sfr = KP_EPI_PERM ? (lane >> 2) : fr;
     const int perm_src = (16 * (lane & 3) + (lane >> 2)) * 4;
@@ -480,16 +482,15 @@ igemm_k1t(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
         a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
         if (q == 0 && m < g.M) {
-          double* dst = stat_s + (st_grp * BM + mrow) * 2;
+          double* dst = stat_s + mrow * 2;
           __hip_atomic_fetch_add(dst, (double)(a * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(dst + 1, (double)(b * sc) * (double)sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 16, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 16, 64));
         vmin = __builtin_fminf(vmin, __shfl_xor(vmin, 32, 64)); vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, 32, 64));
         if (q == 0 && m < g.M) {
-          unsigned* mm = mmk + (((size_t)m * g.groups + st_grp) * st_nsplit + st_j) * 2;
-          atomicMin(mm, key_of_float(vmin * sc));
-          atomicMax(mm + 1, key_of_float(vmax * sc));
+          __hip_atomic_fetch_min(mm_s + mrow * 2, key_of_float(vmin * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_max(mm_s + mrow * 2 + 1, key_of_float(vmax * sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }

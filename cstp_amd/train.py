@@ -6,6 +6,7 @@ deferred to ``StepOutput.to_host()``, called when the driver prints/logs)."""
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -111,22 +112,45 @@ class StagedAllReduce:
     the arena.  On two ranks the result equals the one-piece reduce bit for bit (a + b in either order); on more ranks a
     ring's summation order depends on the element's position in the message, as it does between DDP's buckets."""
 
-    def __init__(self, model, flat_grad):
+    def __init__(self, model, flat_grad, staged=None):
         inner = model.module if hasattr(model, "module") else model
-        slices = inner.grad_stage_slices() if hasattr(inner, "grad_stage_slices") else None
+        # CSTP_STAGED_ALLREDUCE=0 selects the one-piece reduce after backward (round-3 ADVICE: kept selectable until the staged
+        # path has been verified bit-equal to it on RCCL with two ranks; gloo: tests/test_dist_gloo.py)
+        if staged is None:
+            staged = os.environ.get("CSTP_STAGED_ALLREDUCE", "1") != "0"
+        slices = inner.grad_stage_slices() if (staged and hasattr(inner, "grad_stage_slices")) else None
         self.flat = flat_grad
         self.slices = slices or [(0, flat_grad.numel())]
         self.inner = inner if slices is not None else None
-        self._works, self._next = [], 0
-        if self.inner is not None:
-            self.inner._grad_stage_cb = self.stage_done
+        self._works, self._next, self._armed = [], 0, False
 
     @staticmethod
     def active() -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def begin(self):
-        self._works, self._next = [], 0
+        """Arm the reducer for ONE backward pass: the model's stage callback points at this object only between begin() and
+        finish()/abort(), so a backward outside a step (a second step object on the same model, a debug or evaluation
+        backward, a step that raised half-way) queues no collective that nobody waits for."""
+        self._drain()
+        self._works, self._next, self._armed = [], 0, True
+        if self.inner is not None:
+            self.inner._grad_stage_cb = self.stage_done
+
+    def _disarm(self):
+        self._armed = False
+        if self.inner is not None and getattr(self.inner, "_grad_stage_cb", None) == self.stage_done:
+            self.inner._grad_stage_cb = None
+
+    def _drain(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def abort(self):
+        """The step failed between begin() and finish(): stop listening and wait for what was already issued."""
+        self._disarm()
+        self._drain()
 
     def _reduce(self, k):
         off, n = self.slices[k]
@@ -143,22 +167,22 @@ class StagedAllReduce:
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
 
     def stage_done(self, i):
-        """autograd hook: stages 0..i are complete (a later stage's hook may fire first when an earlier one had no hook)."""
-        if not self.active():
+        """autograd hook: stages 0..i are complete (a later stage's hook may fire first when an earlier one had no hook).
+        A no-op when the reducer is not armed, and a stage index never moves the cursor backwards."""
+        if not self._armed or not self.active():
             return
         while self._next <= i and self._next < len(self.slices) - 1:
             self._reduce(self._next)
             self._next += 1
 
     def finish(self):
+        self._disarm()
         if not self.active():
             return self.flat
         while self._next < len(self.slices):
             self._reduce(self._next)
             self._next += 1
-        for w in self._works:
-            w.wait()                      # the current stream waits for the collective
-        self._works = []
+        self._drain()                     # the current stream waits for every collective
         self.flat.mul_(1.0 / dist.get_world_size())
         return self.flat
 
@@ -205,8 +229,13 @@ class PretrainStep:
         sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
         if self._reducer is not None:
             self._reducer.begin()
-        with sync_ctx:
-            out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
+        try:
+            with sync_ctx:
+                out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
+        except BaseException:
+            if self._reducer is not None:
+                self._reducer.abort()
+            raise
         if self._reducer is not None:
             self._reducer.finish()
         gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None

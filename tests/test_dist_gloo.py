@@ -217,7 +217,8 @@ def _worker_pretrain_step(rank, port, q):
     ntx = NTXentLoss(device="cpu", batch_size=8, temperature=0.5, kernel=kern)
     step = PretrainStep(ddp, opt, w, clip_grad_norm=True, ntxent=ntx, ntxent_weight=ntw, cross_entropy=F.cross_entropy)
     assert step._flat_grad is model._arenas["grad"]
-    assert step._reducer is not None and len(step._reducer.slices) == 2 and model._grad_stage_cb is not None
+    # the reducer listens only between begin() and finish(): outside a step the model carries no callback (round-3 ADVICE)
+    assert step._reducer is not None and len(step._reducer.slices) == 2 and model._grad_stage_cb is None
     x1, x2, lab = _stub_data()
     sl = slice(4 * rank, 4 * rank + 4)
     outs = []
@@ -274,14 +275,34 @@ def _worker_staged_allreduce(rank, port, q):
             return [(700, 303), (400, 300), (16, 384), (0, 16)]          # completion order; together they tile the arena
     m = M()
     red = StagedAllReduce(m, flat)
-    assert m._grad_stage_cb is not None and len(red.slices) == 4
+    assert m._grad_stage_cb is None and len(red.slices) == 4
+    red.stage_done(2)                      # a backward outside begin() / finish(): no collective is queued
+    assert red._next == 0 and red._works == []
     red.begin()
-    m._grad_stage_cb(0)
+    cb = m._grad_stage_cb                  # (what a forward pass captures into its autograd hooks)
+    assert cb is not None
+    cb(0)
     assert red._next == 1
-    m._grad_stage_cb(2)                    # stage 1 had no hook of its own: reduced together with stage 2
+    cb(2)                                  # stage 1 had no hook of its own: reduced together with stage 2
+    assert red._next == 3 and len(red._works) == 3
+    cb(1)                                  # a stale index never moves the cursor backwards
     assert red._next == 3 and len(red._works) == 3
     out = red.finish()                     # the last slice + wait + mean
     same = bool(torch.equal(out, ref))
+    assert m._grad_stage_cb is None and red._works == []
+    cb(3)                                  # a hook that fires after finish() (debug backward): disarmed, nothing issued
+    assert red._works == []
+    # a step that fails half-way: abort() waits for what was issued and stops listening; the next begin() starts clean
+    flat3 = flat.clone()
+    red3 = StagedAllReduce(m, flat3)
+    red3.begin()
+    m._grad_stage_cb(1)
+    assert len(red3._works) == 2
+    red3.abort()
+    assert red3._works == [] and m._grad_stage_cb is None and not red3._armed
+    # CSTP_STAGED_ALLREDUCE=0 / staged=False: the one-piece reduce
+    red4 = StagedAllReduce(m, flat.clone(), staged=False)
+    assert len(red4.slices) == 1 and red4.inner is None
     # no hook at all (a model without stage marks): finish() reduces everything
     flat2 = torch.randn(1003, generator=torch.Generator().manual_seed(100 + rank), dtype=torch.float32)
     ref2 = allreduce_mean_(flat2.clone())
