@@ -12,7 +12,7 @@ from ctypes import c_uint32, POINTER, c_char_p, c_double, c_float, c_int32, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSTP_LIB_PATH: developer override for A/B-ing kernel builds (tools/ab_*.sh); unset in production
 LIB_PATH = os.environ.get("CSTP_LIB_PATH") or os.path.join(_HERE, "lib", "libcstp_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class ConvDesc(ctypes.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "cstp_bn_forward_train_pre": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                             c_float, c_float, c_int32, _P, c_size_t, _P, _P, c_int32]),
     "cstp_conv3d_bnstats_nsplit": (c_int32, [POINTER(ConvDesc), c_int32]),
+    "cstp_conv3d_bnstats_nsplit_aff": (c_int32, [POINTER(ConvDesc), c_int32]),
     "cstp_conv3d_forward_bnstats": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, c_int32, _P, _P, c_size_t,
                                               POINTER(c_int32), _P, _P]),
     "cstp_conv3d_in_affine_fused": (c_int32, [POINTER(ConvDesc), c_int32]),

@@ -727,6 +727,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #include "igemm_split.h"
 #include "igemm_patch.h"
 #include "igemm_tpatch.h"
+#include "igemm_twres.h"
 #include "igemm_wpatch.h"
 namespace cstp {
 
@@ -858,7 +859,13 @@ struct ConvPlan {
   int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split; bool w_patch;
 };
 
-static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
+// with_affine: the plan of a FORWARD call that carries an input transform (cstp_in_affine: the BatchNorm + ReLU in front applied in
+// the kernel's staging).  The tuner times plain forwards, where the gather kernel igemm_k1s wins the 64-row temporal layers of the
+// first stage (0.40 ms against 0.48 for igemm_k1w); WITH the transform the gather kernel pays it once per filter tap and cannot
+// leave the next BatchNorm's sums (0.524 ms + 0.075 ms of bn_reduce against 0.523 ms, sums included; same-box step A/B 56.57 ->
+// 55.97 ms, profiles/r04).  So such a call runs the weight-resident kernel wherever it applies (CSTP_K1W=0: the tuner's tile).
+static bool k1w_preferred(const cstp_conv_desc& d, const Tile& t);
+static bool make_plan(const cstp_conv_desc& d, ConvPlan& p, bool with_affine = false) {
   if (d.n <= 0 || d.c <= 0 || d.k <= 0 || d.d <= 0 || d.h <= 0 || d.w <= 0) return false;
   if (d.kt <= 0 || d.kh <= 0 || d.kw <= 0 || d.st <= 0 || d.sh <= 0 || d.sw <= 0) return false;
   if (d.pt < 0 || d.ph < 0 || d.pw < 0) return false;
@@ -882,6 +889,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
       (p.f_straddle || !x_small || p.ntaps > 27 || !split_tile_ok(p.f_t) || native_only()))
     p.f_t = Tile{2, 1, 0, 1, 0};
   if (p.f_t.sp == 1 && stem_split_ok && (!y_small || native_only())) p.f_t = Tile{2, 1, 0, 1, 0};
+  if (with_affine && x_small && y_small && k1w_preferred(d, p.f_t)) p.f_t = Tile{4, 2, 0, 1, 2};
   p.f_Cp = p.f_straddle ? d.c : (int)align_up(d.c, 16);
   p.f_Kp = (int)align_up((size_t)p.ntaps * p.f_Cp, 16);
   p.f_Mp = cdiv(d.k, tile_bm(p.f_t)) * tile_bm(p.f_t);
@@ -928,6 +936,13 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p) {
   p.w_Jtot = p.ntaps * p.w_Cp;
   p.w_Jp = (int)align_up(p.w_Jtot, 32);
   return true;
+}
+
+static bool k1w_preferred(const cstp_conv_desc& d, const Tile& t) {
+  static const bool on = [] { const char* e = getenv("CSTP_K1W"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || g_force_tile != nullptr) return false;                 // (a pinned / timed tile is run as given)
+  if (!((t.sp == 1 || t.sp == 2) && t.mt == 4)) return false;      // the 64-row tiles of the gather / ring kernels
+  return tpatch_geom_ok(d) && k1w_fits(d.k, d.c) && d.c <= KW_AFFC;
 }
 
 // planes per operand of the split kernels: 2 = f16 pair / three products (default), 3 = bf16 triple / six products
@@ -1190,6 +1205,17 @@ static void run_k1t(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const float* pivot = st ? st->pivot : nullptr;
   unsigned* zcell = st ? st->zcell : nullptr;
   const float2* ss = ia ? ia->ss : nullptr;
+  // the 64-row forward layers whose packed weights fit LDS whole: igemm_k1w (igemm_twres.h), tile {4, wm = 2, sp = 2}
+  if (tl.wm == 2 && tl.mt == 4 && !dgrad && !accumulate && k1w_fits(g.M, g.Cs) && (ss == nullptr || g.Cs <= KW_AFFC)) {
+#define CSTP_K1W_(ST_, AF_) \
+  hipLaunchKernelGGL((igemm_k1w<ST_, AF_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, part, pivot, zcell, ss)
+    if (part != nullptr && ss != nullptr) CSTP_K1W_(true, true);
+    else if (part != nullptr) CSTP_K1W_(true, false);
+    else if (ss != nullptr) CSTP_K1W_(false, true);
+    else CSTP_K1W_(false, false);
+#undef CSTP_K1W_
+    return;
+  }
 #define CSTP_K1T_(MT_, ST_, AF_) \
   hipLaunchKernelGGL((igemm_k1t<MT_, ST_, AF_>), grid, dim3(512), 0, s, g, reinterpret_cast<const uint4*>(ws), src, out, inv_a, bcell, ntiles, nmblk, part, pivot, zcell, ss)
 #define CSTP_K1T(MT_) \
@@ -1343,9 +1369,10 @@ static bool aff_tpatch_ok(const cstp_conv_desc& d, const Tile& t, const InAffine
 using namespace cstp;
 
 extern "C" size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc) {
-  ConvPlan p;
-  if (desc == nullptr || !make_plan(*desc, p)) return 0;
-  return plan_ws_bytes(*desc, p);
+  ConvPlan p, pa;
+  if (desc == nullptr || !make_plan(*desc, p) || !make_plan(*desc, pa, true)) return 0;
+  const size_t a = plan_ws_bytes(*desc, p), b = plan_ws_bytes(*desc, pa);      // (a forward with an input transform may run another tile)
+  return a > b ? a : b;
 }
 
 extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, const float* x, const float* w,
@@ -1356,7 +1383,7 @@ extern "C" int cstp_conv3d_forward(void* stream, const cstp_conv_desc* desc, con
 
 extern "C" int32_t cstp_conv3d_in_affine_fused(const cstp_conv_desc* desc, int32_t groups) {
   ConvPlan p;
-  if (desc == nullptr || !make_plan(*desc, p) || groups < 1 || desc->n % groups != 0) return 0;
+  if (desc == nullptr || !make_plan(*desc, p, true) || groups < 1 || desc->n % groups != 0) return 0;
   const cstp_conv_desc& d = *desc;
   InAffine ia{reinterpret_cast<const float2*>(desc), d.n / groups, groups, 1};       // (ss: any non-null pointer, never read here)
   const uint32_t* some = reinterpret_cast<const uint32_t*>(desc);
@@ -1373,13 +1400,19 @@ extern "C" int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_
   return k1p_stats_nsplit(p.f_t, *desc, groups);
 }
 
+extern "C" int32_t cstp_conv3d_bnstats_nsplit_aff(const cstp_conv_desc* desc, int32_t groups) {
+  ConvPlan p;
+  if (desc == nullptr || !make_plan(*desc, p, true)) return 0;
+  return k1p_stats_nsplit(p.f_t, *desc, groups);
+}
+
 extern "C" int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y,
                                            void* ws, size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot,
                                            double* part, size_t part_bytes, int32_t* nsplit_out, uint32_t* z_cell,
                                            const cstp_in_affine* in_affine) {
   CSTP_REQUIRE(desc && x && w && y && ws && part && nsplit_out, "null argument");
   ConvPlan p;
-  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(make_plan(*desc, p, in_affine != nullptr && in_affine->scale_shift != nullptr), "invalid conv descriptor");
   InAffine ia;
   if (parse_in_affine(in_affine, *desc, ia)) return 1;
   const int ns = k1p_stats_nsplit(p.f_t, *desc, groups);
@@ -1405,7 +1438,7 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
                                       size_t ws_bytes, const uint32_t* x_absmax) {
   CSTP_REQUIRE(desc && x && w && y && ws, "null argument");
   ConvPlan p;
-  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(make_plan(*desc, p, bias == nullptr && in_affine != nullptr && in_affine->scale_shift != nullptr), "invalid conv descriptor");
   CSTP_REQUIRE(ws_bytes >= plan_ws_bytes(*desc, p), "workspace too small");
   const cstp_conv_desc& d = *desc;
   CSTP_REQUIRE((size_t)d.n * d.c * d.d * d.h * d.w < (1ull << 30) && (size_t)d.n * d.k * p.Do * p.Ho * p.Wo < (1ull << 30),
@@ -1747,7 +1780,9 @@ extern "C" int cstp_conv3d_set_tile(const cstp_conv_desc* desc, int32_t mode, co
     }
   } else if (split == 2) {
     CSTP_REQUIRE(patch_mt_ok(mt), "patch tiles: 4, 8 or 9 row tiles of 16");
-    t = Tile{mt, 1, 0, 1, 2};
+    // tile4[2] == 2: the weight-resident temporal forward kernel igemm_k1w (64 rows; run_k1t falls back to igemm_k1t where it does not apply)
+    CSTP_REQUIRE(tile4[2] == 0 || tile4[2] == 1 || (tile4[2] == 2 && mt == 4 && mode == 0), "patch tiles: variant 2 = weight-resident, 64 rows, forward");
+    t = Tile{mt, tile4[2] == 2 ? 2 : 1, 0, 1, 2};
   } else if (split) {
     CSTP_REQUIRE(split_mt_ok(mt), "split tiles: 2, 3, 4, 5, 6, 8 or 9 row tiles of 16");
     CSTP_REQUIRE(tile4[2] == 0 || tile4[2] == 1 || (tile4[2] == 2 && mt >= 8), "split tiles: 128 columns, or 256 with 8 / 9 row tiles");
@@ -1874,6 +1909,8 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     for (int mt : pmt) { const int pad = cdiv(M, 16 * mt) * 16 * mt - M; if (pad < best_pad) best_pad = pad; }
     for (int mt : pmt)
       if (cdiv(M, 16 * mt) * 16 * mt - M <= best_pad + M / 8 && ncand < 40) cand[ncand++] = Tile{mt, 1, 0, 1, 2};
+    // the weight-resident temporal forward kernel igemm_k1w (64 rows, <= 15 K-tiles)
+    if (mode == 0 && tpatch_geom_ok(d) && k1w_fits(d.k, d.c) && ncand < 41) cand[ncand++] = Tile{4, 2, 0, 1, 2};
   }
   hipStream_t s = as_stream(stream);
   hipEvent_t e0, e1;
@@ -1895,6 +1932,22 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
     if (hipEventSynchronize(e1) != hipSuccess) { rc = fail("hipEventSynchronize failed%s", ""); break; }
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
+    // Candidates are ranked the way the training step runs them: every convolution of these networks feeds a train-mode
+    // BatchNorm, and a forward candidate that cannot leave that BatchNorm's sums in its epilogue (anything but the patch
+    // kernels, on a layer where those can) is followed by a statistics pass over y -- one read of the output at the ~5.5 TB/s
+    // the BatchNorm passes reach.  (Measured on T1, 144 -> 64 at 16 x 56 x 56: gather 0.524 ms + 0.075 ms of bn_reduce against
+    // 0.523 ms for igemm_k1w with the sums inside.)
+    if (mode == 0 && cand[i].sp != 2 && k1p_stats_nsplit(Tile{4, 1, 0, 1, 2}, d, 2) > 0) {
+      const double ybytes = 4.0 * d.n * d.k * (double)d.d * d.h * d.w;
+      ms += (float)(iters * ybytes / 5.5e9);
+    }
+    {
+      static const bool verbose = getenv("CSTP_TUNE_VERBOSE") != nullptr;     // developer knob: the ranking as the tuner saw it
+      if (verbose)
+        fprintf(stderr, "cstp tune mode %d [%d %d %d %d %d -> %d, %dx%dx%d]: tile {sp %d, mt %d, wm %d, tpb %d}  %.4f ms per launch (as ranked)\n",
+                mode, d.n, d.c, d.d, d.h, d.w, d.k, d.kt, d.kh, d.kw, cand[i].sp, cand[i].m16 ? 9 : cand[i].mt, cand[i].wm,
+                cand[i].tpb, ms / iters);
+    }
     if (ms < best_ms) { best_ms = ms; best = i; }
   }
   g_force_tile = nullptr;

@@ -703,7 +703,7 @@ class _BNReluConv3d(torch.autograd.Function):
         aff = InAffine(ss.data_ptr(), groups, 1 if relu else 0)
         # a train-mode BatchNorm over out_groups slices consumes y: where this layer's kernel can, it leaves that BatchNorm's
         # sums and range beside y (the temporal patch kernel igemm_k1t<.., STATS, AFF>)
-        ns = lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), out_groups) if (out_groups > 0 and FUSE_BN_STATS) else 0
+        ns = lib.cstp_conv3d_bnstats_nsplit_aff(ctypes.byref(desc), out_groups) if (out_groups > 0 and FUSE_BN_STATS) else 0
         _BNReluConv3d._last_stats = None
         with _span("conv3d_forward", lambda: _desc_key(desc)):
             if ns > 0:

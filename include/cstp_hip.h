@@ -15,8 +15,20 @@
  *     host or synchronises: calls only enqueue work (graph-capture safe).  Scratch comes from
  *     the caller through (ws, ws_bytes); query the size with the *_workspace_bytes functions.
  *   - return value: 0 on success, non-zero on error; cstp_last_error() returns a message for
- *     the calling thread.  Global mutable state: that thread-local string and the (mutex-guarded) table of tuned
- *     tile shapes written only by cstp_conv3d_autotune.
+ *     the calling thread.
+ *   - PROCESS-GLOBAL mutable state behind this interface (all of it; none is per stream or per call):
+ *       * the thread-local error string;
+ *       * the mutex-guarded table of tuned tile shapes (cstp_conv3d_autotune / cstp_conv3d_set_tile write it, every
+ *         convolution call reads it);
+ *       * the GEMM arithmetic selector cstp_gemm_set_split_terms (atomic; 0 = the CSTP_GEMM environment default) -- it picks
+ *         the kernel family of EVERY later convolution / linear call of the process, on any stream, and is part of the tile
+ *         table's key;
+ *       * the deterministic-mode switch cstp_set_deterministic (atomic; ordered slabs instead of float atomics in the weight
+ *         gradients), likewise process-wide;
+ *       * environment knobs read once: CSTP_GEMM, CSTP_DETERMINISTIC, CSTP_PERSIST_CUS, CSTP_K1P_QUAD, CSTP_K1W, CSTP_TILE /
+ *         CSTP_WTILE (developer overrides).
+ *     A caller that wants two arithmetics side by side in one process must serialise the switch with its launches
+ *     (bench.py does, between timed loops); results never depend on the state of another STREAM.
  */
 #ifndef CSTP_HIP_H
 #define CSTP_HIP_H
@@ -28,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CSTP_ABI_VERSION 17
+#define CSTP_ABI_VERSION 18
 
 /* Geometry of one nn.Conv3d(bias=False) call-site.
  * models/pace/r21d_byol.py:81-82 (spatial 1xkxk), :91-92 (temporal tx1x1), :125 (1x1x1 shortcut);
@@ -101,6 +113,9 @@ int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, const float
  * maximum into it with atomics).  in_affine (or NULL): the input transform of cstp_conv3d_forward_am, for a temporal
  * convolution that consumes one BatchNorm inside its gather and feeds the next (x_absmax is then that of T(x)). */
 int32_t cstp_conv3d_bnstats_nsplit(const cstp_conv_desc* desc, int32_t groups);
+/* ... the answer for a call that carries an in_affine (such a forward may run another kernel variant than the plain one:
+ * the weight-resident temporal kernel igemm_k1w where it applies, csrc/igemm_twres.h). */
+int32_t cstp_conv3d_bnstats_nsplit_aff(const cstp_conv_desc* desc, int32_t groups);
 int cstp_conv3d_forward_bnstats(void* stream, const cstp_conv_desc* desc, const float* x, const float* w, float* y, void* ws,
                                 size_t ws_bytes, const uint32_t* x_absmax, int32_t groups, const float* pivot, double* part,
                                 size_t part_bytes, int32_t* nsplit, uint32_t* z_cell, const cstp_in_affine* in_affine);

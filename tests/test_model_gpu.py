@@ -116,26 +116,32 @@ def test_hip_path_matches_reference_golden(name):
         assert rel(out["loss_total"], g[pre + "loss_total"]) < tol
         assert rel(out["ce"], g[pre + "ce"]) < tol
         assert rel(out["logits"], g[pre + "logits"]) < tol
-        assert rel(out["grad_norm"], g[pre + "grad_norm"]) < gtol
         gn = np.array([out["grad_norms"].get(k, -1.0) for k in pkeys])
-        assert rel(gn, g[pre + "grad_norms"]) < gtol
-        assert cs_err(checksums(model, keys), g[pre + "state_cs"]) < STATE_TOLS[s] * STATE_SCALE.get(name, 1.0)
         # state indices are torch.optim.SGD(model.parameters())'s: the frozen target tensors keep their rows (no state)
         mcs = momentum_checksums(opt)
         assert mcs.shape == g[pre + "mom_cs"].shape
-        assert cs_err(mcs, g[pre + "mom_cs"]) < gtol
+        errs = {"grad_norm": (rel(out["grad_norm"], g[pre + "grad_norm"]), TOLS[s][1], GRAD_SCALE.get(name, 1.0)),
+                "grad_norms": (rel(gn, g[pre + "grad_norms"]), TOLS[s][1], GRAD_SCALE.get(name, 1.0)),
+                "state_cs": (cs_err(checksums(model, keys), g[pre + "state_cs"]), STATE_TOLS[s], STATE_SCALE.get(name, 1.0)),
+                "mom_cs": (cs_err(mcs, g[pre + "mom_cs"]), TOLS[s][1], GRAD_SCALE.get(name, 1.0))}
         if s == 1 and (name in GRAD_SCALE or name in STATE_SCALE):
-            # the fixtures whose bars are widened (R(2+1)D-34: noise amplification through 66 train-mode BN layers): the HIP
-            # path must stay within a fixed factor of what STOCK PyTorch fp32 -- the oracle, run here on the host -- leaves
-            # against the same fp64 truth, so that an arithmetic regression cannot hide behind the widened bar (round-2 ADVICE)
+            # The fixtures whose bars test_oracle_golden.py widens FOR STOCK PYTORCH FP32 (R(2+1)D-34: noise amplification through
+            # 66 train-mode BN layers).  The widened bar alone never passes the HIP path (round-3 VERDICT weak-3): a quantity is
+            # either under the UNWIDENED bar -- where the HIP path sat on all of them at the end of round 3,
+            # profiles/r03/r34_hip_vs_stock_fp32.log -- or it is under the widened one AND within a fixed factor of what stock
+            # fp32 (the oracle, run here on the host) leaves against the same fp64 truth, so an arithmetic regression cannot
+            # hide behind the widening.
             _, oinfos, ostates, omoms, _ = run_oracle(name, steps=1)
             ogn = np.array([float(oinfos[0]["grads"][k].norm()) if k in oinfos[0]["grads"] else -1.0 for k in pkeys])
-            pairs = {"grad_norms": (rel(gn, g[pre + "grad_norms"]), rel(ogn, g[pre + "grad_norms"]), TOLS[1][1]),
-                     "state_cs": (cs_err(checksums(model, keys), g[pre + "state_cs"]), cs_err(ostates[0], g[pre + "state_cs"]), STATE_TOLS[1]),
-                     "mom_cs": (cs_err(mcs, g[pre + "mom_cs"]), cs_err(omoms[0], g[pre + "mom_cs"]), TOLS[1][1])}
-            print("%s: (HIP error, stock-fp32 error, unwidened bar) %s" % (name, pairs))
-            for what, (e_hip, e_fp32, base) in pairs.items():
-                assert e_hip < base or e_hip < HIP_VS_FP32 * e_fp32, (name, what, e_hip, e_fp32)
+            e_fp32 = {"grad_norms": rel(ogn, g[pre + "grad_norms"]), "state_cs": cs_err(ostates[0], g[pre + "state_cs"]),
+                      "mom_cs": cs_err(omoms[0], g[pre + "mom_cs"])}
+            e_fp32["grad_norm"] = e_fp32["grad_norms"]
+            print("%s: (HIP error, stock-fp32 error, unwidened bar) %s" % (name, {k: (v[0], e_fp32[k], v[1]) for k, v in errs.items()}))
+            for what, (e_hip, base, scale) in errs.items():
+                assert e_hip < base or (e_hip < base * scale and e_hip < HIP_VS_FP32 * e_fp32[what]), (name, what, e_hip, e_fp32[what])
+        else:
+            for what, (e_hip, base, scale) in errs.items():
+                assert e_hip < base * scale, (name, s, what, e_hip)
     # BN counters: online/target nets see two forwards per step (r21d_byol.py:359-366)
     msd = model.state_dict()
     assert int(msd["online_net.bn1.num_batches_tracked"]) == 2 * nsteps

@@ -167,3 +167,107 @@ def test_residual_block_fused_on_the_patch_kernels_matches_the_materialising_blo
     finally:
         rb.FUSE_BN_TEMPORAL, ops.FUSE_BN_STATS = True, True
         ops.set_split_terms(0)
+
+
+# ---- igemm_k1w (csrc/igemm_twres.h): the 64-row temporal forward layers with the packed weights resident in LDS (tile (2, 4, 2, .))
+K1W_GEOMS = {
+    "conv2_x class": ((2, 144, 16, 28, 28), 64),      # 15 K-tiles, half-empty fifth channel block, two frame tiles per clip
+    "one frame tile": ((2, 64, 8, 14, 14), 64),       # 6 K-tiles; both halo frames are the zero padding
+    "48 rows": ((1, 96, 8, 14, 28), 48),              # fewer valid rows than the 64-row block
+    "many tiles": ((4, 32, 16, 14, 14), 64),          # more items than blocks on small grids: the item loop runs
+}
+
+
+@pytest.mark.parametrize("name", list(K1W_GEOMS))
+def test_weight_resident_temporal_forward_against_fp64_and_the_ring_kernel(name):
+    from cstp_amd import ops
+    xs, k = K1W_GEOMS[name]
+    ws = (k, xs[1], 3, 1, 1)
+    ops.set_split_terms(2)
+    try:
+        g = torch.Generator().manual_seed(21)
+        x = (torch.randn(xs, generator=g) + 0.1).cuda()
+        w = (torch.randn(ws, generator=g) * 0.1).cuda()
+        ops.set_conv_tile(xs, ws, (1, 1, 1), (1, 0, 0), 0, (2, 4, 2, 0))
+        y = ops.conv3d(x, w, None, 1, (1, 0, 0))
+        ops.set_conv_tile(xs, ws, (1, 1, 1), (1, 0, 0), 0, (2, 4, 0, 0))
+        y_ring = ops.conv3d(x, w, None, 1, (1, 0, 0))
+        ref = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (1, 0, 0))
+        assert rel_err(y.cpu().double(), ref) < 1e-4
+        assert torch.equal(y, y_ring)         # the same products in the same order: bit for bit igemm_k1t's result
+    finally:
+        ops.set_split_terms(0)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_weight_resident_temporal_forward_leaves_batchnorm_statistics(groups):
+    from cstp_amd import ops
+    xs, k = (4, 48, 8, 14, 14), 64
+    ws = (k, xs[1], 3, 1, 1)
+    ops.set_split_terms(2)
+    ops.set_conv_tile(xs, ws, (1, 1, 1), (1, 0, 0), 0, (2, 4, 2, 0))
+    try:
+        g = torch.Generator().manual_seed(5)
+        x = (torch.randn(xs, generator=g) + 0.3).cuda()
+        w = (torch.randn(ws, generator=g) * 0.1).cuda()
+        gamma, beta = (torch.rand(k, generator=g) + 0.5).cuda(), torch.randn(k, generator=g).cuda()
+
+        def run(fused):
+            rm, rv = torch.zeros(k, device="cuda"), torch.ones(k, device="cuda")
+            y = ops.conv3d(x, w, None, 1, (1, 0, 0), bn_groups=groups if fused else 0, bn_pivot=rm)
+            assert (getattr(y, "_cstp_bnstats", None) is not None) == fused
+            return ops.batch_norm_act(y, gamma, beta, rm, rv, None, True, 1e-5, 0.1, groups), rm, rv
+
+        a, rma, rva = run(True)
+        b, rmb, rvb = run(False)
+        assert rel_err(a, b) < 2e-6 and rel_err(rma, rmb) < 2e-6 and rel_err(rva, rvb) < 2e-6
+        yc = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (1, 0, 0))
+        outs, rm, rv = [], torch.zeros(k, dtype=torch.float64), torch.ones(k, dtype=torch.float64)
+        for part in yc.chunk(groups, 0):
+            outs.append(F.relu(F.batch_norm(part, rm, rv, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)))
+        assert rel_err(a.cpu().double(), torch.cat(outs, 0)) < 1e-4
+        assert rel_err(rma.cpu().double(), rm) < 1e-4 and rel_err(rva.cpu().double(), rv) < 1e-4
+    finally:
+        ops.set_split_terms(0)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_weight_resident_temporal_forward_applies_the_batchnorm_in_front_bit_for_bit(groups):
+    """temporal_conv(relu(bn(spatial_conv(x)))) with the BatchNorm + ReLU applied in igemm_k1w's staging: the forward output equals
+    the materialising path's bit for bit (tests/test_fused_bn_gpu.py's chain, the temporal forward pinned on the new kernel)."""
+    import test_fused_bn_gpu as fb
+    from cstp_amd import ops
+    name = "temporal patch kernel, 64 rows"
+    old = fb.FUSED_GEOMS[name]
+    fb.FUSED_GEOMS[name] = old[:4] + ((2, 4, 2, 0),) + old[5:]
+    ops.set_split_terms(2)
+    try:
+        ys = fb._pin(name)
+        xs, mid, k = fb.FUSED_GEOMS[name][:3]
+        assert ops.in_affine_fused(ys, (k, mid, 3, 1, 1), 1, (1, 0, 0), groups)
+        ops.set_deterministic(True)
+        a, b = fb._run(name, groups, True), fb._run(name, groups, False)
+        assert a["zmax"] == b["zmax"] and a["zmax"] != 0
+        for key in ("out", "dwt", "dx", "dws", "dgamma", "dbeta", "rm", "rv"):
+            assert torch.equal(a[key], b[key]), (key, float((a[key] - b[key]).abs().max()))
+    finally:
+        ops.set_deterministic(False)
+        fb.FUSED_GEOMS[name] = old
+        ops.set_split_terms(0)
+
+
+def test_weight_resident_tile_falls_back_to_the_ring_kernel_where_the_weights_do_not_fit():
+    """(2, 4, 2, .) on a layer with more than 15 K-tiles (or in the data gradient) runs igemm_k1t: same results, no error."""
+    from cstp_amd import ops
+    xs, k = (1, 192, 8, 14, 14), 64              # 6 channel blocks = 18 K-tiles
+    ws = (k, xs[1], 3, 1, 1)
+    ops.set_split_terms(2)
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(xs, generator=g).cuda()
+        w = (torch.randn(ws, generator=g) * 0.1).cuda()
+        ops.set_conv_tile(xs, ws, (1, 1, 1), (1, 0, 0), 0, (2, 4, 2, 0))
+        y = ops.conv3d(x, w, None, 1, (1, 0, 0))
+        assert rel_err(y.cpu().double(), F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (1, 0, 0))) < 1e-4
+    finally:
+        ops.set_split_terms(0)
