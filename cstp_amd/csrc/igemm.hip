@@ -729,6 +729,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #include "igemm_tpatch.h"
 #include "igemm_twres.h"
 #include "igemm_wpatch.h"
+#include "igemm_wtpatch.h"
 namespace cstp {
 
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
@@ -775,6 +776,16 @@ static bool wpatch_geom_ok(const cstp_conv_desc& d) {
   // (stream rows and frame counts stay below 2^25 and the divisors below 129: the kernel divides by multiplication)
   if ((long)d.n * d.d * (d.h + 1) * (d.w + 2) >= (1l << 25) || d.h + 1 > 128 || d.d > 128) return false;
   return 2 * (d.w + 2) + 66 <= 5 * 64;
+}
+// the temporal weight-gradient kernel igemm_k2t (igemm_wtpatch.h): 3x1x1, stride 1, padding (1,0,0), f16 pair, frames of whole
+// 32-position chunks (one aligned 128-byte line per channel, frame and chunk); item / frame-line counts below 2^26 (the kernel
+// divides by multiplication)
+static bool twpatch_geom_ok(const cstp_conv_desc& d) {
+  if (!(d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 0 && d.pw == 0))
+    return false;
+  if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
+  if ((d.h * d.w) % 32 != 0 || d.d > 255) return false;
+  return (long)d.n * (d.h * d.w / 32) * (d.d + 1) < (1l << 26);
 }
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
@@ -856,7 +867,7 @@ struct ConvPlan {
   // dgrad
   Tile d_t; int d_Cp, d_Mp, d_Kp;
   // wgrad
-  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split; bool w_patch;
+  int w_mt, w_blocks, w_Cp, w_Jtot, w_Jp; bool w_straddle; bool w_split; bool w_patch; bool w_tpatch;
 };
 
 // with_affine: the plan of a FORWARD call that carries an input transform (cstp_in_affine: the BatchNorm + ReLU in front applied in
@@ -907,6 +918,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p, bool with_affine = f
   p.w_blocks = 2048;   // ~8 blocks per CU: measured 12 % faster than 4 per CU over the R18 layer set
   p.w_split = false;
   p.w_patch = false;
+  p.w_tpatch = false;
   {
     Tile wt;
     bool have_wt = lookup_tuned(d, 2, wt);
@@ -919,6 +931,7 @@ static bool make_plan(const cstp_conv_desc& d, ConvPlan& p, bool with_affine = f
     }
     if (have_wt && wt.sp == 2) {       // igemm_k2p: x resident in LDS across the nine taps (144-row blocks, f16 pair)
       p.w_patch = !p.w_straddle && x_small && y_small && wpatch_geom_ok(d);
+      p.w_tpatch = !p.w_straddle && x_small && y_small && twpatch_geom_ok(d);       // igemm_k2t: the temporal layers' stream kernel
       have_wt = false;
     }
     if (have_wt) {
@@ -1337,6 +1350,37 @@ static int run_k2p(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, co
   return 0;
 }
 
+// weight gradient of the temporal layers on streams of 32-position chunks (igemm_k2t): one block per (144 x-channels, 64 dY
+// channels, item range); slab(s) as igemm_k2p
+static int run_k2t(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, const float* x, const float* dy, float* dwp,
+                   const unsigned* xcell, const unsigned* dycell, bool det, size_t det_stride, int* nslabs_out,
+                   const float2* ss, int aff_npg, int aff_groups, int aff_relu) {
+  WTGeom g;
+  g.C = d.c; g.M = d.k;
+  g.nrb = cdiv(d.c, WP_BM); g.ncb = cdiv(d.k, 64);
+  g.D = d.d; g.HW = d.h * d.w; g.Nb = d.n;
+  g.nchunk = g.HW / 32;
+  g.nitems = d.n * g.nchunk;
+  g.Jp = p.w_Jp; g.Cp = p.w_Cp;
+  g.mg_fp1 = (unsigned)((1ull << 32) / (unsigned)(d.d + 1) + 1);
+  g.mg_nchunk = (unsigned)((1ull << 32) / (unsigned)g.nchunk + 1);
+  g.aff_npg = aff_npg; g.aff_groups = aff_groups; g.aff_relu = aff_relu;
+  const int ncombo = g.nrb * g.ncb;
+  int ns = cu_count() / ncombo;
+  if (ns < 1) ns = 1;
+  if (ns > g.nitems) ns = g.nitems;
+  if (det && ns > DET_MAX_SPLITS) ns = DET_MAX_SPLITS;
+  g.iper = cdiv(g.nitems, ns);
+  g.nsplit = cdiv(g.nitems, g.iper);
+  dim3 grid((unsigned)align_up((size_t)ncombo * g.nsplit, 8), 1, 1);
+  if (ss != nullptr)
+    hipLaunchKernelGGL(igemm_k2t<true>, grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0, ss);
+  else
+    hipLaunchKernelGGL(igemm_k2t<false>, grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0, ss);
+  *nslabs_out = det ? g.nsplit : 1;
+  return 0;
+}
+
 static int parse_in_affine(const cstp_in_affine* a, const cstp_conv_desc& d, InAffine& o) {
   o.ss = nullptr; o.npg = 1; o.groups = 1; o.relu = 0;
   if (a == nullptr || a->scale_shift == nullptr) return 0;
@@ -1390,7 +1434,8 @@ extern "C" int32_t cstp_conv3d_in_affine_fused(const cstp_conv_desc* desc, int32
   const long S = (long)p.Do * p.Ho * p.Wo;
   const bool fwd = (p.f_t.sp == 1 && !p.f_straddle && aff_split_ok(d, ia, some, S, tile_bn(p.f_t))) ||
                    aff_tpatch_ok(d, p.f_t, ia, some, nullptr, nullptr);
-  const bool wgr = p.w_split && !p.w_straddle && !p.w_patch && aff_split_ok(d, ia, some, S, 32);
+  const bool wgr = (p.w_split && !p.w_straddle && !p.w_patch && !p.w_tpatch && aff_split_ok(d, ia, some, S, 32)) ||
+                   (p.w_tpatch && groups <= 2);
   return fwd && wgr ? 1 : 0;
 }
 
@@ -1619,6 +1664,28 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
     CSTP_LAUNCH_CHECK();
     return 0;
   }
+  if (p.w_tpatch && (ia.ss == nullptr || (ia.groups <= 2 && x_absmax != nullptr))) {
+    // igemm_k2t: the temporal layers, both operands staged once (AFF: the transform of x inside; x_absmax is then T(x)'s)
+    const size_t det_stride_p = det ? slab_al / sizeof(float) : 0;
+    int ns_max = cu_count() / (cdiv(d.c, WP_BM) * cdiv(d.k, 64));
+    ns_max = ns_max < 1 ? 1 : (ns_max > DET_MAX_SPLITS ? DET_MAX_SPLITS : ns_max);
+    const size_t slabs_bytes_p = slab_al * (det ? ns_max : 1);
+    unsigned* cells_p = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + slabs_bytes_p);
+    if (hipMemsetAsync(dwp, 0, slabs_bytes_p + 256, s) != hipSuccess) return fail("hipMemsetAsync failed%s", "");
+    const size_t nx = (size_t)d.n * d.c * d.d * d.h * d.w, ny = (size_t)d.n * d.k * p.Do * p.Ho * p.Wo;
+    if (x_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(nx)), dim3(256), 0, s, x, nx, cells_p);
+    if (dy_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(ny)), dim3(256), 0, s, dy, ny, cells_p + 1);
+    const unsigned* xc = x_absmax != nullptr ? x_absmax : cells_p;
+    const unsigned* dyc = dy_absmax != nullptr ? dy_absmax : cells_p + 1;
+    int nslabs = 1;
+    run_k2t(s, d, p, x, dy, dwp, xc, dyc, det, det_stride_p, &nslabs, ia.ss, ia.npg, ia.groups, ia.relu);
+    CSTP_LAUNCH_CHECK();
+    const size_t tot_p = (size_t)d.k * d.c * p.ntaps;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(pack_grid(tot_p)), dim3(256), 0, s, dwp, dw, d.k, d.c, p.ntaps, p.w_Cp, p.w_Jp,
+                       xc, dyc, nslabs, det_stride_p, accumulate ? 1 : 0);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   // the fused input transform: on the f16-pair gather kernel (igemm_k2s<.., AFF>) where aff_split_ok, else the native kernel
   // with its analytic tile
   const bool aff_split = ia.ss != nullptr && p.w_split && !p.w_straddle && aff_split_ok(d, ia, x_absmax, (long)p.Do * p.Ho * p.Wo, 32);
@@ -1710,6 +1777,10 @@ extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, 
   CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
   if (mode == 2 && p.w_patch) {       // igemm_k2p: 144 rows x (32 channels x 9 taps), f16 pair
     out4[0] = WP_BM; out4[1] = 288; out4[2] = 2; out4[3] = 0;
+    return 0;
+  }
+  if (mode == 2 && p.w_tpatch) {      // igemm_k2t: 144 x-channels x (64 dY channels x 3 taps), f16 pair
+    out4[0] = WP_BM; out4[1] = 192; out4[2] = 2; out4[3] = 0;
     return 0;
   }
   if (mode == 2) {
@@ -1845,7 +1916,7 @@ extern "C" int cstp_conv3d_autotune(void* stream, const cstp_conv_desc* desc, in
       if (cdiv(d.k, 144) * 144 - d.k < pad) smt = 9;
       for (int blocks = 4; blocks <= 16; blocks *= 2) wc[nw++] = Tile{smt, blocks, 0, 0, 1};
     }
-    if (allow_split2 && !stem && wpatch_geom_ok(d)) wc[nw++] = Tile{9, 1, 0, 0, 2};      // igemm_k2p
+    if (allow_split2 && !stem && (wpatch_geom_ok(d) || twpatch_geom_ok(d))) wc[nw++] = Tile{9, 1, 0, 0, 2};      // igemm_k2p / igemm_k2t
     hipStream_t s2 = as_stream(stream);
     hipEvent_t a0, a1;
     if (hipEventCreate(&a0) != hipSuccess || hipEventCreate(&a1) != hipSuccess) return fail("hipEventCreate failed%s", "");

@@ -271,3 +271,88 @@ def test_weight_resident_tile_falls_back_to_the_ring_kernel_where_the_weights_do
         assert rel_err(y.cpu().double(), F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, (1, 0, 0))) < 1e-4
     finally:
         ops.set_split_terms(0)
+
+
+# ---- igemm_k2t (csrc/igemm_wtpatch.h): the temporal layers' weight gradient on streams of 32-position chunks (mode-2 tile (2, 9, ., .))
+K2T_GEOMS = {
+    "T1 class": ((2, 144, 8, 8, 16), 64),          # exactly one (144, 64) pair; 4 chunks per frame
+    "two column blocks": ((2, 48, 4, 8, 8), 80),   # 80 dY channels = 64 + 16; 48 x channels of a 144-row block
+    "two row blocks": ((1, 160, 4, 8, 4), 32),     # 160 x channels = 144 + 16; one chunk per frame; 32 dY channels
+    "long clip": ((1, 32, 16, 4, 8), 64),          # 16 frames, one chunk
+    "many items": ((6, 64, 2, 16, 16), 48),        # 48 items of three stream frames each: blocks walk item ranges
+    "stem class": ((2, 83, 4, 8, 8), 64),          # 83 x channels (the stem's temporal layer): a ragged last 4-channel piece
+}
+
+
+@pytest.mark.parametrize("name", list(K2T_GEOMS))
+def test_temporal_stream_weight_gradient_against_fp64(name):
+    from cstp_amd import _lib, ops
+    xs, k = K2T_GEOMS[name]
+    GEOMS["_k2t"] = (xs, k, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    ops.set_split_terms(2)
+    try:
+        _run("_k2t", {0: (1, 4, 0, 0), 1: (1, 4, 0, 0), 2: (2, 9, 1, 0)})
+        out = (ctypes.c_int32 * 4)()
+        desc = ops._desc(xs, (k, xs[1], 3, 1, 1), (1, 1, 1), (1, 0, 0))
+        _lib.check(_lib.load().cstp_conv3d_query_tile(ctypes.byref(desc), 2, out), "query")
+        assert list(out)[:3] == [144, 192, 2]              # the stream kernel is what ran
+    finally:
+        ops.set_split_terms(0)
+        del GEOMS["_k2t"]
+
+
+def test_temporal_stream_weight_gradient_deterministic_mode_is_reproducible():
+    from cstp_amd import ops
+    xs, k = K2T_GEOMS["many items"]
+    ws = (k, xs[1], 3, 1, 1)
+    ops.set_split_terms(2)
+    ops.set_deterministic(True)
+    ops.set_conv_tile(xs, ws, (1, 1, 1), (1, 0, 0), 2, (2, 9, 1, 0))
+    try:
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(xs, generator=g).cuda()
+        dy = torch.randn((xs[0], k) + xs[2:], generator=g).cuda()
+        res = []
+        for _ in range(2):
+            w = torch.zeros(ws, device="cuda", requires_grad=True)
+            ops.conv3d(x, w, None, 1, (1, 0, 0)).backward(dy)
+            ops._join_side_streams()
+            res.append(w.grad.clone())
+        assert torch.equal(res[0], res[1])
+        wd = torch.zeros(ws, dtype=torch.float64, requires_grad=True)
+        F.conv3d(x.double().cpu(), wd, None, 1, (1, 0, 0)).backward(dy.double().cpu())
+        assert rel_err(res[0].cpu().double(), wd.grad) < 1e-4
+    finally:
+        ops.set_deterministic(False)
+        ops.set_split_terms(0)
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_temporal_stream_weight_gradient_with_the_batchnorm_in_front_inside(groups):
+    """The fused chain of tests/test_fused_bn_gpu.py with the temporal weight gradient on igemm_k2t<AFF>: bit for bit the
+    materialising path's (which runs igemm_k2t on the written tensor) in deterministic mode, fp64 within the 1e-4 bar."""
+    import test_fused_bn_gpu as fb
+    from cstp_amd import ops
+    fb.FUSED_GEOMS["_k2t"] = ((4, 16, 7, 16, 16), 144, 64, 9, (1, 4, 0, 0), (2, 9, 1, 0))      # 7 frames x 256 positions: whole 224-position tiles per group AND whole 32-position chunks
+    ops.set_split_terms(2)
+    ops.set_deterministic(True)
+    try:
+        ys = fb._pin("_k2t")
+        xs, mid, k = fb.FUSED_GEOMS["_k2t"][:3]
+        assert ops.in_affine_fused(ys, (k, mid, 3, 1, 1), 1, (1, 0, 0), groups)
+        a, b = fb._run("_k2t", groups, True), fb._run("_k2t", groups, False)
+        assert a["zmax"] == b["zmax"] and a["zmax"] != 0
+        for key in ("out", "dwt", "dx", "dws", "dgamma", "dbeta", "rm", "rv"):
+            assert torch.equal(a[key], b[key]), (key, float((a[key] - b[key]).abs().max()))
+        x, w_s, w_t, gamma, beta = [t.double().requires_grad_(True) for t in fb._inputs("_k2t")]
+        y = F.conv3d(x, w_s, None, 1, (0, 1, 1))
+        rm, rv = torch.zeros(gamma.numel(), dtype=torch.float64), torch.ones(gamma.numel(), dtype=torch.float64)
+        z = torch.cat([F.relu(F.batch_norm(p, rm, rv, gamma, beta, True, 0.1, 1e-5)) for p in y.chunk(groups, 0)], 0)
+        out = F.conv3d(z, w_t, None, 1, (1, 0, 0))
+        dy = (torch.rand(out.shape, generator=torch.Generator().manual_seed(3)) * 2 - 1).double()
+        out.backward(dy)
+        assert rel_err(a["dwt"], w_t.grad) < 1e-4 and rel_err(a["out"], out.detach()) < 1e-4
+    finally:
+        ops.set_deterministic(False)
+        fb.FUSED_GEOMS.pop("_k2t", None)
+        ops.set_split_terms(0)
