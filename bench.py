@@ -51,7 +51,7 @@ ARITH_NAME = {0: "native f32 MFMA", 1: "native f32 MFMA", 2: "2xf16-split (22-bi
 DEPTH, B_LOCAL, T, HW = 18, 16, 16, 112
 LOSS_WEIGHT = (0.1, 1.0, 1.0, 0.0, 0.0)
 NTXENT_WEIGHT = 1.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_dominant_kernel.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04", "pmc_dominant_kernel.json")
 
 
 class KernelTimers:
@@ -218,6 +218,7 @@ def main():
     bn_key = (nb, 144, fr * h2 * h2, 2, False, True)                     # BN + ReLU behind S1 (two view groups)
     specs = {"S1 fwd": ("conv3d_forward", d_s1), "S1 dgrad": ("conv3d_backward_data", d_s1),
              "S1 wgrad": ("conv3d_backward_weight", d_s1), "T1 fwd": ("conv3d_forward", d_t1),
+             "T1 dgrad": ("conv3d_backward_data", d_t1), "T1 wgrad": ("conv3d_backward_weight", d_t1),
              "stem S0 fwd": ("conv3d_forward", d_s0), "stem S0 wgrad": ("conv3d_backward_weight", d_s0),
              "BN+ReLU fwd (144 ch)": ("bn_forward", bn_key), "BN+ReLU bwd (144 ch)": ("bn_backward", bn_key)}
     timers = KernelTimers(specs, torch.cuda.current_stream().cuda_stream)
@@ -279,7 +280,11 @@ def main():
             row = {"kernel": name, "launches_timed": len(timers.pairs[name]), "avg_ms": ms}
             if what.startswith("conv3d"):
                 flops, nbytes = conv_work(*key)
-                tile = query(key, mode_of[what])
+                from cstp_amd import r21d_byol as _rb2
+                # the temporal layer's forward carries the BatchNorm + ReLU in front as an in_affine (mode 3: its own variant)
+                t1_aff = name == "T1 fwd" and _rb2.FUSE_BN_TEMPORAL and \
+                    ops.in_affine_fused(d_t1[:5], (d_t1[5], d_t1[1]) + tuple(d_t1[6:9]), d_t1[9:12], d_t1[12:15], 2)
+                tile = query(key, 3 if t1_aff else mode_of[what])
                 terms = tile[2]
                 peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS[terms] if terms in SPLIT_PRODUCTS else F32_MFMA_PEAK_TFLOPS
                 row.update({"bound": "mfma", "tile": "%dx%d" % (tile[0], tile[1]), "arithmetic": ARITH_NAME[terms],
@@ -312,6 +317,8 @@ def main():
                                           "reads x and dy and writes dx (ReLU mask recomputed from x)")})
             row["hbm_tbs"] = nbytes / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             row["frac_hbm"] = row["hbm_tbs"] / HBM_PEAK_TBS
+            if what.startswith("conv3d") and row["frac_hbm"] > row["frac_compute"]:
+                row["bound"] = "hbm"           # (the temporal layers: 66 FLOP per byte, below the f16-pair ridge of 105)
             kernels.append(row)
         timers.pairs["S1 fwd"] = dom_pairs
         # ---- the other two arithmetics, same process, same step (each has its own class of tuned tiles)

@@ -1772,9 +1772,10 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
 
 extern "C" int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4) {
   CSTP_REQUIRE(desc && out4, "null argument");
-  CSTP_REQUIRE(mode == 0 || mode == 1 || mode == 2, "mode must be 0 (forward), 1 (backward_data) or 2 (backward_weight)");
+  CSTP_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (forward), 1 (backward_data), 2 (backward_weight) or 3 (forward with an in_affine)");
   ConvPlan p;
-  CSTP_REQUIRE(make_plan(*desc, p), "invalid conv descriptor");
+  CSTP_REQUIRE(make_plan(*desc, p, mode == 3), "invalid conv descriptor");
+  if (mode == 3) mode = 0;
   if (mode == 2 && p.w_patch) {       // igemm_k2p: 144 rows x (32 channels x 9 taps), f16 pair
     out4[0] = WP_BM; out4[1] = 288; out4[2] = 2; out4[3] = 0;
     return 0;

@@ -29,6 +29,10 @@
 #ifndef KP_RING6
 #define KP_RING6 0    // 1: six-slot weight ring at 64 rows (measured neutral: 58.19 vs 58.11 ms/step -- the weight DMA is not what the short K-tiles wait for)
 #endif
+#ifndef KP_GROUP3
+#define KP_GROUP3 0   // 1: 64-row tiles run THREE K-tiles (one filter row) per barrier through a six-slot weight ring -- a K-tile of 42 products
+#endif                // per wave lasts 672 matrix cycles.  MEASURED NEUTRAL (S1 data gradient 0.856 vs 0.834 ms, step 54.97 vs 54.92 ms same-box,
+                      // parity green): neither the barrier nor the weight-fragment wait is what the short K-tiles lose their time to
 #ifndef KP_EPI_PERM
 #define KP_EPI_PERM 1  // epilogue: lanes re-ordered (ds_bpermute) so that the four lanes of a channel are neighbours: a 16-lane
 #endif                 // group of a store then writes 4 runs of 64 bytes instead of 16 pieces of 16 bytes (one per channel row)
@@ -150,7 +154,8 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
   // Weight ring: three K-tiles where LDS is full (128 / 144 rows); SIX at 64 rows -- a K-tile of 42 products per consumer wave
   // lasts ~0.3 us, and a weight piece requested two K-tiles ahead (0.6 us) is not back from L2 when its K-tile starts: the
   // DMA waves' wait, and behind it the barrier, set the K-tile time.  Five K-tiles of lead cost 24 KB.
-  constexpr int RING = KP_RING6 && MT == 4 ? 6 : 3;
+  constexpr int GK = (KP_GROUP3 && MT == 4) ? 3 : 1;           // K-tiles per barrier
+  constexpr int RING = (GK == 3 || (KP_RING6 && MT == 4)) ? 6 : 3;
   __shared__ uint4 smem[RING * A_U4 + 2 * P_U4 + 2 * (BM / 4) + (STATS ? BM + BM / 2 : 0)];
   uint4* const ring = smem;
   uint4* const patch = smem + RING * A_U4;
@@ -247,6 +252,21 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         if (++d_kt == nkt) { d_kt = 0; ++d_it; item_of(d_it, tl_unused, d_mblk); }
       }
     };
+    if constexpr (GK == 3) {
+      // groups of three K-tiles: group g + 1 is requested into the three slots group g - 1 was read from and has the whole of
+      // group g's products (~1 us) to land; this wave has nothing else to do, so it simply waits for it
+      dma_next(); dma_next(); dma_next();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int ngroups = nitems * nkt / 3;
+#pragma unroll 1
+      for (int gq = 0; gq < ngroups; ++gq) {
+        if (!(KP_DIAG & 2)) { dma_next(); dma_next(); dma_next(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) dma_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,8 +484,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
           for (int tap = 0; tap < 9; ++tap) {
             if (tap >= 4 && tap - 4 < QR) q_store(pb ^ 1, tap - 4, rq[tap - 4]);
             if (tap < QR) q_load(tap, stage ? (last_cb ? qv_nxt[tap] : qv_cur[tap]) : OOB, ncb_, rq[tap]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (GK == 1 || tap % 3 == 2) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+            }
           }
           pb ^= 1;
         }
@@ -520,8 +542,10 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
               b_load(vo, ncb_, rb[rl]);
             }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
+          if (GK == 1 || tap % 3 == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
         }
         pb ^= 1;
       }
@@ -685,11 +709,16 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       for (int j = 0; j < KP_NTW; ++j) {
         // column tile j + 2 (past the last: tiles 0, 1 of the next K-tile; past the item's last K-tile harmless reads,
         // issued again at the top of the next item) is requested now; tile j + 3's address is computed among tile j's products
-        issue_b(bh[(PH + j + 2) % 3], bl[(PH + j + 2) % 3], addr_n);
+        // GK == 3: the staging waves write the NEXT channel block's patch until the barrier behind this block's last K-tile
+        // (tap 8), so its first two column tiles are NOT requested ahead of that barrier (the K loop requests them behind it)
+        const bool hold = GK == 3 && PH == 2 && j + 2 >= KP_NTW && tap == 8;
+        if (!hold) issue_b(bh[(PH + j + 2) % 3], bl[(PH + j + 2) % 3], addr_n);
         if (j + 3 < KP_NTW) addr_n = b_addr(j + 3, Bp, ts);
         else addr_n = b_addr(j + 3 - KP_NTW, Bn, nts);
         // tile j (requested two groups ago) has landed once at most the four youngest reads are outstanding
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        if (!hold) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (j == KP_NTW - 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 bhj = bh[(PH + j) % 3], blj = bl[(PH + j) % 3];
 #if KP_DIAG & 4
@@ -736,7 +765,7 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
 #endif
       // (no drain in front of the barrier: every read of this K-tile's ring slot and of this channel block's patch buffer has
       // been waited for above; the two tiles in flight belong to the next K-tile and stay in flight across the barrier)
-      __builtin_amdgcn_s_barrier();
+      if (GK == 1 || PH == 2) __builtin_amdgcn_s_barrier();
 #if KP_DIAG & 16
       s_bar += KP_T() - t_b0;
 #endif
@@ -746,6 +775,14 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
       ktile(std::integral_constant<int, 0>{});
       ktile(std::integral_constant<int, 1>{});
       ktile(std::integral_constant<int, 2>{});
+      if constexpr (GK == 3) {
+        if (tap == 0 && kt + 3 < nkt) {               // a new channel block of this item: its patch is complete behind the barrier
+          const unsigned Bq = patch_lds + pb * (P_U4 * 16);
+          issue_b(bh[0], bl[0], b_addr(0, Bq, 0));
+          issue_b(bh[1], bl[1], b_addr(1, Bq, 0));
+          addr_n = b_addr(2, Bq, 0);
+        }
+      }
     }
     // the next item's prologue re-issues into buffers 0 and 1: the two reads still in flight must have landed before that
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

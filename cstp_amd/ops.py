@@ -91,7 +91,7 @@ def _triple(v) -> Tuple[int, int, int]:
 # candidate set the entries were chosen from: bump it whenever a kernel variant is added or changed, and stale tables are
 # ignored.
 AUTOTUNE = os.environ.get("CSTP_AUTOTUNE", "1") != "0"
-TUNE_REV = 4
+TUNE_REV = 5
 _tuned = set()
 _TABLE_ENV = os.environ.get("CSTP_TUNE_TABLE", "")
 TUNE_TABLE_PATH = None if _TABLE_ENV == "0" else (

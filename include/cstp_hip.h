@@ -154,8 +154,9 @@ int32_t cstp_gemm_get_split_terms(void);
 /* Which kernel variant the next forward (mode 0) / backward_data (mode 1) / backward_weight (mode 2) call with this
  * descriptor will run: out[0] = rows per block tile, out[1] = positions (mode 2: (tap, channel) columns) per block tile,
  * out[2] = 0 for the native f32 MFMA kernel, else the number of terms each operand is split into by the split kernel (2 or
- * 3, see cstp_gemm_set_split_terms), out[3] = K-tiles per barrier (mode 2: split-K block target / 256).  Reporting only
- * (bench.py names the kernels and picks their roofline peaks with it). */
+ * 3, see cstp_gemm_set_split_terms), out[3] = K-tiles per barrier (mode 2: split-K block target / 256).  mode 3 = a forward
+ * call that carries an in_affine (it may run another variant than the plain forward: cstp_conv3d_bnstats_nsplit_aff).
+ * Reporting only (bench.py names the kernels and picks their roofline peaks with it). */
 int cstp_conv3d_query_tile(const cstp_conv_desc* desc, int32_t mode, int32_t* out4);
 
 /* The TUNED entry of one geometry and direction in cstp_conv3d_set_tile's encoding (tile4[0] = -1 when the geometry has

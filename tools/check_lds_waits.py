@@ -64,6 +64,7 @@ def check_function(name, body):
         j, hops = k + 1, 0
         found = None
         steps = 0
+        live = set(dst)    # destination registers that still hold the fragment (any later write to one ends its life there)
         while j < len(ins) and steps < 6000:
             steps += 1
             _, (m2, d2, s2), l2 = ins[j]
@@ -71,10 +72,13 @@ def check_function(name, body):
                 mm = LGKM.search(l2)
                 if mm and int(mm.group(1)) <= later:
                     ok_wait = True
-            if s2 & dst:
+            if s2 & live:
                 found = l2
                 break
             if d2 >= dst and m2.startswith("ds_read"):       # the ring slot is re-loaded: this read's value was never used past here
+                break
+            live -= d2       # (an MFMA's accumulator operand appears among its sources too, so an overwritten fragment register is
+            if not live:     #  never mistaken for a use; a fragment the compiler recycles as a temporary before reloading it is dead)
                 break
             if m2.startswith(("ds_", "s_load", "s_buffer_load")):
                 later += 1

@@ -25,9 +25,11 @@ bash tools/pmc_s1.sh fwd > $O/pmc_fwd.txt 2>&1
 bash tools/pmc_s1.sh dgrad > $O/pmc_dgrad.txt 2>&1
 bash tools/pmc_s1.sh wgrad > $O/pmc_wgrad.txt 2>&1
 for m in fwd dgrad wgrad; do bash tools/pmc_s1.sh $m T1 > $O/pmc_T1_$m.txt 2>&1; done
+# ... and the S1 / T1 kernels in the instantiations the step runs (sums in the epilogues, in_affine): round-3 VERDICT weak-5
+bash tools/pmc_chain.sh > $O/pmc_chain_S1_T1.txt 2>&1
 # the stamped record bench.py reports roofline.traffic from (commit: CSTP_COMMIT, the box has no .git)
 python3 tools/write_pmc_record.py $O/pmc_fwd.txt $O/pmc_dominant_kernel.json
-mkdir -p profiles/r03 && cp $O/pmc_dominant_kernel.json profiles/r03/pmc_dominant_kernel.json
+mkdir -p profiles/r04 && cp $O/pmc_dominant_kernel.json profiles/r04/pmc_dominant_kernel.json
 python3 bench.py > $O/bench_default_run.json.log 2>$O/bench_default_run.err
 tail -1 $O/bench_default_run.json.log | cut -c1-300
 head -14 $O/bench_last3steps_serial.txt

@@ -41,7 +41,7 @@ rec = {
     "algorithmic_bytes_per_launch": in_bytes + out_bytes,
     "FETCH_SIZE_KB_reported": vals["FETCH_SIZE"],
     "FETCH_SIZE_note": "gfx950 reports half the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM/rocprofv3 section; "
-                       "calibrated x2 with tools/calib_fetch.py on 4 B/lane loads, the width of this kernel's activation gathers)",
+                       "the x2 holds for 16 B/lane loads -- this kernel's QUAD staging since round 4 -- and was calibrated with tools/calib_fetch.py on 4 B/lane loads too)",
     "WRITE_SIZE_KB_reported": vals["WRITE_SIZE"],
     "counters": vals,
     "command": "rocprofv3 --pmc <counter set> --kernel-trace --output-format csv -- python3 tools/one_conv.py fwd 32   "
