@@ -784,8 +784,8 @@ static bool twpatch_geom_ok(const cstp_conv_desc& d) {
   if (!(d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 1 && d.ph == 0 && d.pw == 0))
     return false;
   if (native_only() || split_planes() != 2 || d.c < 16 || d.k < 16) return false;
-  if ((d.h * d.w) % 32 != 0 || d.d > 255) return false;
-  return (long)d.n * (d.h * d.w / 32) * (d.d + 1) < (1l << 26);
+  if ((d.h * d.w) % 16 != 0 || d.d > 255) return false;      // chunks of 32 positions, or of 16 (28 x 28 frames)
+  return (long)d.n * (d.h * d.w / 16) * (d.d + 1) < (1l << 26);
 }
 static inline bool split_mt_ok(int mt) { return mt == 2 || mt == 3 || mt == 4 || mt == 5 || mt == 6 || mt == 8 || mt == 9; }
 static inline bool split_tile_ok(const Tile& t) { return split_mt_ok(t.mt) && (t.wm != 2 || t.mt >= 8); }
@@ -1359,7 +1359,8 @@ static int run_k2t(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, co
   g.C = d.c; g.M = d.k;
   g.nrb = cdiv(d.c, WP_BM); g.ncb = cdiv(d.k, 64);
   g.D = d.d; g.HW = d.h * d.w; g.Nb = d.n;
-  g.nchunk = g.HW / 32;
+  const int chunk = (g.HW % 32 == 0) ? 32 : 16;
+  g.nchunk = g.HW / chunk;
   g.nitems = d.n * g.nchunk;
   g.Jp = p.w_Jp; g.Cp = p.w_Cp;
   g.mg_fp1 = (unsigned)((1ull << 32) / (unsigned)(d.d + 1) + 1);
@@ -1373,10 +1374,10 @@ static int run_k2t(hipStream_t s, const cstp_conv_desc& d, const ConvPlan& p, co
   g.iper = cdiv(g.nitems, ns);
   g.nsplit = cdiv(g.nitems, g.iper);
   dim3 grid((unsigned)align_up((size_t)ncombo * g.nsplit, 8), 1, 1);
-  if (ss != nullptr)
-    hipLaunchKernelGGL(igemm_k2t<true>, grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0, ss);
-  else
-    hipLaunchKernelGGL(igemm_k2t<false>, grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0, ss);
+#define CSTP_K2T(AF_, CH_) hipLaunchKernelGGL((igemm_k2t<AF_, CH_>), grid, dim3(512), 0, s, g, dy, x, dwp, xcell, dycell, det ? det_stride : (size_t)0, ss)
+  if (chunk == 32) { if (ss != nullptr) CSTP_K2T(true, 32); else CSTP_K2T(false, 32); }
+  else { if (ss != nullptr) CSTP_K2T(true, 16); else CSTP_K2T(false, 16); }
+#undef CSTP_K2T
   *nslabs_out = det ? g.nsplit : 1;
   return 0;
 }

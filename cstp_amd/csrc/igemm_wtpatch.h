@@ -28,7 +28,7 @@ struct WTGeom {
   int C, M;          // channels of x (z) / of dY
   int nrb, ncb;      // 144-channel blocks of x, 64-channel blocks of dY
   int D, HW, Nb;     // frames per clip, frame size (a multiple of 32), clips
-  int nchunk;        // HW / 32
+  int nchunk;        // HW / chunk
   int nitems;        // Nb * nchunk work items
   int nsplit, iper;  // blocks per (row block, column block) pair, items per block
   int Jp, Cp;        // slab row pitch; channels per tap in the slab's column order j = tap * Cp + c
@@ -36,7 +36,9 @@ struct WTGeom {
   int aff_npg, aff_groups, aff_relu;    // AFF: clips per BatchNorm group of x, groups (<= 2), ReLU
 };
 
-template <bool AFF>
+// CH = positions per chunk: 32 (one aligned 128-byte line per channel and frame; a K-step = one frame) or 16 (frame sizes that are
+// multiples of 16 only -- 28 x 28: a K-step = two frames of half lines, a tap = a shift of 16 stream rows)
+template <bool AFF, int CH>
 __global__ void __launch_bounds__(512, 2)
 igemm_k2t(const WTGeom g, const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dwp,
           const unsigned* __restrict__ xcell, const unsigned* __restrict__ dycell, size_t det_stride,
@@ -58,7 +60,8 @@ igemm_k2t(const WTGeom g, const float* __restrict__ dy, const float* __restrict_
   I = I < g.iper ? I : g.iper;
   if (I <= 0) return;
   const int D = g.D, HW = g.HW, FP1 = D + 1;
-  const int NI = (I * FP1 * 32 + 63) >> 6;             // intervals (64 rows = two K-steps) of this block's stream
+  static_assert(CH == 32 || CH == 16, "chunk");
+  const int NI = (I * FP1 * CH + 63) >> 6;             // intervals (64 rows = two K-steps) of this block's stream
   const int c0 = rb * WP_BM, m0 = cbk * 64;
 
   // the ring starts all zero: the first K-steps read rows the stream has not written (against z rows that are zero -- the
@@ -89,13 +92,13 @@ igemm_k2t(const WTGeom g, const float* __restrict__ dy, const float* __restrict_
     // dY: nch = M), or OOB (halo frame, past the block's last item); *grp: the BatchNorm group of the row's clip
     auto row_base = [&](int k, int nch, int* grp) __attribute__((always_inline)) -> unsigned {
       const unsigned sr = (unsigned)(k * 64 + lane);
-      const unsigned L = sr >> 5, p = sr & 31u;
+      const unsigned L = sr / (unsigned)CH, p = sr & (unsigned)(CH - 1);
       const unsigned it = __umulhi(L, g.mg_fp1), ll = L - it * (unsigned)FP1;
       const unsigned ig = (unsigned)i_begin + it;
       const unsigned nb = __umulhi(ig, g.mg_nchunk), ch = ig - nb * (unsigned)g.nchunk;
       const bool ok = it < (unsigned)I && ll >= 1;
       if (grp != nullptr) *grp = ok ? (int)(nb / (unsigned)g.aff_npg) : 0;
-      return ok ? ((nb * (unsigned)nch * D + (ll - 1)) * HW + ch * 32u + p) * 4u : OOB;
+      return ok ? ((nb * (unsigned)nch * D + (ll - 1)) * HW + ch * (unsigned)CH + p) * 4u : OOB;
     };
     // channels past the tensors' last ones are CLAMPED (finite values whose products land in slab cells nobody reads);
     // the channel rides in the load's scalar offset (wave-uniform)
@@ -206,14 +209,14 @@ igemm_k2t(const WTGeom g, const float* __restrict__ dy, const float* __restrict_
   const int a_lo = wp_aslot(r_lo, lp), a_hi = wp_aslot(r_hi, lp);
   const uint2* Y0 = Yr[ct >> 1][0];
   const uint2* Y1 = Yr[ct >> 1][1];
-  // my three taps: ring slot of my k-rows r_lo / r_hi shifted by (1 - dt) * 32 rows, swizzle included (it reads row bits 2..4,
-  // which neither the shift nor a K-step changes); a K-step moves the slots on by 32 rows = 256 slots (mod the ring)
+  // my three taps: ring slot of my k-rows r_lo / r_hi shifted by (1 - dt) * CH rows, swizzle included (it reads row bits 2..4,
+  // which a K-step of 32 rows does not change); a K-step moves the slots on by 32 rows = 256 slots (mod the ring)
   int I_lo[3], I_hi[3];
 #pragma unroll
   for (int tp = 0; tp < 3; ++tp) {
-    const int sh = (1 - tp) * 32;
-    I_lo[tp] = ((sh + r_lo) & (WT_RING - 1)) * 8 + wp_slot(r_lo, (ct & 1) * 4 + lp);
-    I_hi[tp] = ((sh + r_hi) & (WT_RING - 1)) * 8 + wp_slot(r_hi, (ct & 1) * 4 + lp);
+    const int sh = (1 - tp) * CH;
+    I_lo[tp] = ((sh + r_lo) & (WT_RING - 1)) * 8 + wp_slot(sh + r_lo, (ct & 1) * 4 + lp);
+    I_hi[tp] = ((sh + r_hi) & (WT_RING - 1)) * 8 + wp_slot(sh + r_hi, (ct & 1) * 4 + lp);
   }
   f32x4 acc[3][9];
 #pragma unroll

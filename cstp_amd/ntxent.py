@@ -26,11 +26,23 @@ def all_gather_with_grad(z: torch.Tensor) -> torch.Tensor:
     # back as the live tensor so that the gradient reaches this rank's embeddings
     out = torch.empty((world * b,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
     zc = z.detach().contiguous()
-    try:
+    # The form of the collective is chosen ONCE FROM THE BACKEND -- identically on every rank -- and real errors propagate.
+    # (Round-3 ADVICE: a try / except around the tensor form let ONE rank fall back to the list form after, say, an
+    # out-of-memory error while its peers had completed the tensor form: mismatched collectives hang the job.)
+    if _tensor_form(z):
         dist.all_gather_into_tensor(out, zc)
-    except (RuntimeError, NotImplementedError):          # a backend without the tensor form
+    else:
         dist.all_gather(list(out.split(b, dim=0)), zc)
     return _PutLocal.apply(out, z, rank * b)
+
+
+def _tensor_form(z: torch.Tensor) -> bool:
+    """all_gather_into_tensor where the backend that serves ``z``'s device has it (RCCL / NCCL: yes; gloo: the list form)."""
+    backend = dist.get_backend()
+    if ":" in backend:              # "cpu:gloo,cuda:nccl": the entry of the tensor's device type
+        kinds = dict(part.split(":") for part in backend.split(","))
+        backend = kinds.get("cuda" if z.is_cuda else "cpu", "gloo")
+    return backend.lower() in ("nccl", "rccl")
 
 
 class _PutLocal(torch.autograd.Function):

@@ -117,9 +117,27 @@ def _load_table():
     return _table
 
 
+_dirty_rank = None        # this process's rank when the table was first marked dirty (the exit hook runs after destroy_process_group)
+
+
 def _is_rank0() -> bool:
+    """Rank 0 of the job -- also at interpreter exit, when the process group is gone and dist.get_rank() would answer 0 on
+    EVERY rank (round-3 ADVICE): the launcher's RANK, else the rank remembered when the table got its first new entry."""
+    env = os.environ.get("RANK")
+    if env is not None and env.isdigit():
+        return int(env) == 0
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank() == 0
+    return _dirty_rank in (None, 0)
+
+
+def _note_dirty() -> None:
+    global _table_dirty, _dirty_rank
+    _table_dirty = True
+    if _dirty_rank is None:
+        import torch.distributed as dist
+        _dirty_rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
 def save_tune_table(path=None) -> bool:
@@ -183,7 +201,7 @@ def _autotune(lib, desc, mode, src, w, out, ws):
     check(lib.cstp_conv3d_get_tile(ctypes.byref(desc), mode, arr), "cstp_conv3d_get_tile")
     if arr[0] >= 0:
         tbl[sk] = [int(v) for v in arr]
-        _table_dirty = True          # written by save_tune_table(): after a step's first call, or at exit
+        _note_dirty()                # written by save_tune_table(): after a step's first call, or at exit
 
 
 import atexit  # noqa: E402
@@ -345,6 +363,8 @@ class GradJoin:
     epilogue: cstp_conv3d_backward_data_acc) and hands autograd None; the last one adds its own and returns the sum.
     A fresh object per forward call; backward order is whatever the autograd engine chooses."""
 
+    _open = []                # joins that hold a partial sum (checked when the backward pass ends)
+
     def __init__(self, n: int):
         self.n, self.count, self.buf = int(n), 0, None
 
@@ -355,12 +375,30 @@ class GradJoin:
             out = plain()
         else:
             accumulate(self.buf)
+            # the accumulating kernel wrote through data_ptr(): tell autograd's version counter (round-3 ADVICE)
+            torch.autograd.graph.increment_version(self.buf)
             out = self.buf
         if self.count < self.n:
+            if self.buf is None:
+                # first contributor: if the others never run (a consumer's input gradient pruned by autograd.grad(inputs=...),
+                # needs_input_grad False on one branch) the partial sum would silently vanish -- an end-of-backward check raises
+                GradJoin._open.append(self)
+                if len(GradJoin._open) == 1:
+                    torch.autograd.Variable._execution_engine.queue_callback(GradJoin._check_closed)
             self.buf = out
             return None
+        if self in GradJoin._open:
+            GradJoin._open.remove(self)
         self.buf, self.count = None, 0
         return out
+
+    @staticmethod
+    def _check_closed():
+        left = [(j.count, j.n) for j in GradJoin._open]
+        GradJoin._open.clear()
+        if left:
+            raise RuntimeError("GradJoin: %d residual joins ended the backward pass with contributors missing %r -- a consumer's "
+                               "input gradient was pruned; the block input's gradient would have been dropped" % (len(left), left))
 
 
 class _Conv3d(torch.autograd.Function):

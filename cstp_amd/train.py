@@ -245,7 +245,7 @@ class PretrainStep:
             # every layer geometry has been seen (and tuned, if the persisted table lacked it) once: all ranks adopt rank
             # 0's tiles so that the same layer runs the same kernel everywhere
             self._tiles_shared = True
-            if self._flat_grad is None or self._flat_grad.is_cuda:
+            if any(p.is_cuda for p in self._inner.parameters()):      # (CPU / stub models never load the HIP library)
                 ops.share_tune_table()
         return out
 

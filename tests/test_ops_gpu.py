@@ -86,6 +86,10 @@ BNS = [
     ((4, 512), False, True),
     ((2, 1024), False, False),
     ((2, 6, 3, 5, 5), True, False),
+    # more than 64 partial sums per channel (nsplit = min(2048 / c, n) = 80) AND a frame size that is not a multiple of 4: the
+    # statistics folded inside the apply passes (BnFin) on the scalar path (round-3 ADVICE)
+    ((80, 8, 5, 3, 3), False, True),
+    ((72, 6, 3, 5, 5), True, True),
 ]
 
 

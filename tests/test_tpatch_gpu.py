@@ -281,6 +281,9 @@ K2T_GEOMS = {
     "long clip": ((1, 32, 16, 4, 8), 64),          # 16 frames, one chunk
     "many items": ((6, 64, 2, 16, 16), 48),        # 48 items of three stream frames each: blocks walk item ranges
     "stem class": ((2, 83, 4, 8, 8), 64),          # 83 x channels (the stem's temporal layer): a ragged last 4-channel piece
+    # frame sizes that are multiples of 16 only: chunks of 16 positions, a K-step = two frames, K-steps straddle items
+    "16-position chunks": ((2, 48, 8, 4, 12), 64),
+    "conv3_x class": ((2, 288, 8, 28, 28), 128),   # 784 positions per frame: two row blocks x two column blocks
 }
 
 
