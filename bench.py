@@ -380,7 +380,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": "spatial conv S1 64->144 1x3x3 @%dx56x56, 2B=%d clips/launch; %dx%d tile, %s; HIP events "
-                                   "around the C-ABI call (incl. the weight pack)" % (fr, nb, tile[0], tile[1], ARITH_NAME[terms]),
+                                   "around the C-ABI call (its weight pack runs with all others of the step from one launch at the step's top: "
+                                   "ops.PackPlan)" % (fr, nb, tile[0], tile[1], ARITH_NAME[terms]),
                          "launches_timed": len(timers.pairs["S1 fwd"]), "avg_launch_ms": k_ms,
                          "algorithmic_gflop_per_launch": flops / 1e9,
                          "kernels": kernels,

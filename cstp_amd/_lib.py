@@ -26,6 +26,12 @@ class InAffine(ctypes.Structure):
     _fields_ = [("scale_shift", c_void_p), ("groups", c_int32), ("relu", c_int32)]
 
 
+class PackRec(ctypes.Structure):
+    """struct cstp_pack_rec: one recorded weight-pack launch (cstp_pack_mode / cstp_pack_recorded / cstp_pack_replay)."""
+    _fields_ = [("kind", c_int32), ("nblocks", c_int32), ("w", c_void_p), ("dst", c_void_p), ("inv_a", c_void_p),
+                ("cells", c_void_p), ("a", c_int32 * 10)]
+
+
 class CstpError(RuntimeError):
     pass
 
@@ -47,6 +53,9 @@ SIGNATURES = {
     "cstp_conv3d_backward_weight_am": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P]),
     "cstp_conv3d_backward_weight_acc": (c_int32, [_P, POINTER(ConvDesc), _P, POINTER(InAffine), _P, _P, _P, c_size_t, _P, _P,
                                                  c_int32]),
+    "cstp_pack_mode": (c_int32, [c_int32]),
+    "cstp_pack_recorded": (c_int32, [POINTER(PackRec), c_int32]),
+    "cstp_pack_replay": (c_int32, [_P, _P, _P, c_int32, c_int32]),
     "cstp_set_deterministic": (c_int32, [c_int32]),
     "cstp_get_deterministic": (c_int32, []),
     "cstp_gemm_set_split_terms": (c_int32, [c_int32]),

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -62,10 +63,10 @@ struct Geom {
 // weight packing: native [k_out][c_in][taps]  ->  K-major GEMM operand, zero padded
 //   forward: Wp[(tap*Cp + c)][m = k_out]        dgrad: Wp[(tap*Cp + k_out)][m = c_in]
 // ------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int kout, int cin,
-                                    int ntaps, int Cp, int Mp, int Kp, int dgrad) {
+__device__ __forceinline__ void pack_native_body(const float* __restrict__ w, float* __restrict__ wp, int kout, int cin,
+                                                 int ntaps, int Cp, int Mp, int Kp, int dgrad, const int blk, const int nblk) {
   const size_t total = (size_t)Kp * Mp;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
     const int m = (int)(i % Mp);
     const int k = (int)(i / Mp);
     const int tap = k / Cp, c = k - tap * Cp;
@@ -79,6 +80,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
     wp[i] = v;
   }
+}
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int kout, int cin,
+                                    int ntaps, int Cp, int Mp, int Kp, int dgrad) {
+  pack_native_body(w, wp, kout, cin, ntaps, Cp, Mp, Kp, dgrad, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // split-K output of the weight-gradient kernels: f32 atomics into ONE slab (default), or a plain store into this split's own
@@ -1079,6 +1084,74 @@ static int pack_grid(size_t total) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
+// ---- weight packs of a whole network pass from ONE launch (cstp_pack_mode / cstp_pack_recorded / cstp_pack_replay, cstp_hip.h).
+// Every weight-pack launch of the convolution entry points goes through one of the three helpers below.  Per calling thread:
+// mode 0 = launch it (default); mode 1 = launch it AND append what was launched to the thread's record list; mode 2 = skip it --
+// the caller has replayed the recorded packs of this very call (same descriptor, same tile table, same weight and workspace
+// pointers) earlier on the stream.  A record IS the launch (kernel kind, pointers, integer arguments, block count), so whatever
+// variant the dispatch picked is what gets replayed.
+static thread_local int tl_pack_mode = 0;
+static thread_local std::vector<cstp_pack_rec> tl_pack_recs;
+
+static void pack_site_split2(hipStream_t s, const float* w, unsigned* wps, float* inv_a, unsigned* cells, int ncells, int kout,
+                             int cin, int ntaps, int Cp, int Mp, int ngroups, int dgrad) {
+  if (tl_pack_mode == 2) return;
+  if (tl_pack_mode == 1) {
+    cstp_pack_rec r{};
+    r.kind = 1; r.nblocks = Mp; r.w = w; r.dst = wps; r.inv_a = inv_a; r.cells = cells;
+    const int a[8] = {ncells, kout, cin, ntaps, Cp, Mp, ngroups, dgrad};
+    memcpy(r.a, a, sizeof(a));
+    tl_pack_recs.push_back(r);
+  }
+  hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(Mp), dim3(256), 0, s, w, wps, inv_a, cells, ncells, kout, cin, ntaps, Cp, Mp,
+                     ngroups, dgrad);
+}
+static void pack_site_patch(hipStream_t s, const float* w, uint4* wpk, float* inv_a, unsigned* cells, int ncells, int kout, int cin,
+                            int ncb, int rows_per_blk, int nblk_rows, int dgrad, int nt) {
+  if (tl_pack_mode == 2) return;
+  if (tl_pack_mode == 1) {
+    cstp_pack_rec r{};
+    r.kind = 2; r.nblocks = nblk_rows; r.w = w; r.dst = wpk; r.inv_a = inv_a; r.cells = cells;
+    const int a[7] = {ncells, kout, cin, ncb, rows_per_blk, dgrad, nt};
+    memcpy(r.a, a, sizeof(a));
+    tl_pack_recs.push_back(r);
+  }
+  hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nblk_rows), dim3(256), 0, s, w, wpk, inv_a, cells, ncells, kout, cin, ncb,
+                     rows_per_blk, dgrad, nt);
+}
+static void pack_site_native(hipStream_t s, const float* w, float* wp, int kout, int cin, int ntaps, int Cp, int Mp, int Kp, int dgrad) {
+  if (tl_pack_mode == 2) return;
+  const int nb = pack_grid((size_t)Kp * Mp);
+  if (tl_pack_mode == 1) {
+    cstp_pack_rec r{};
+    r.kind = 3; r.nblocks = nb; r.w = w; r.dst = wp; r.inv_a = nullptr; r.cells = nullptr;
+    const int a[7] = {kout, cin, ntaps, Cp, Mp, Kp, dgrad};
+    memcpy(r.a, a, sizeof(a));
+    tl_pack_recs.push_back(r);
+  }
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, s, w, wp, kout, cin, ntaps, Cp, Mp, Kp, dgrad);
+}
+
+// block b runs record r with first[r] <= b < first[r + 1] as that record's block b - first[r]
+__global__ void __launch_bounds__(256)
+pack_replay_kernel(const cstp_pack_rec* __restrict__ recs, const int* __restrict__ first, int n) {
+  int lo = 0, hi = n - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {                                    // (uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const cstp_pack_rec R = recs[lo];
+  const int lb = b - first[lo];
+  const int* a = R.a;
+  if (R.kind == 1)
+    pack_split2_body<0>(R.w, reinterpret_cast<unsigned*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lb);
+  else if (R.kind == 2)
+    pack_patch_body(R.w, reinterpret_cast<uint4*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], lb);
+  else
+    pack_native_body(R.w, reinterpret_cast<float*>(R.dst), a[0], a[1], a[2], a[3], a[4], a[5], a[6], lb, R.nblocks);
+}
+
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h); npg = clips per BatchNorm group
 struct InAffine { const float2* ss; int npg, groups, relu; };
 
@@ -1126,15 +1199,19 @@ static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, con
   }
   unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
-  hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(g.Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
-                     d.k, d.c, ntaps, g.Cp, g.Mp, Kp / 16, DGRAD ? 1 : 0);
+  pack_site_split2(s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1, d.k, d.c, ntaps, g.Cp, g.Mp, Kp / 16, DGRAD ? 1 : 0);
   if constexpr (!DGRAD) {
     if (ia != nullptr && ia->ss != nullptr) {         // the gathered tensor is act(src * scale + shift); src_absmax is ITS maximum (checked by the caller)
       launch_k1s_np<false, 2, true>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a, src_absmax, ia);
       return;
     }
   }
-  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  if (src_absmax == nullptr) {
+    // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
+    //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
+    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  }
   launch_k1s_np<DGRAD, 2>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a,
                           src_absmax != nullptr ? src_absmax : cells);
 }
@@ -1150,11 +1227,11 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
   float* xp = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + packed);
   unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
-  hipLaunchKernelGGL(pack_weights_split2_kernel, dim3(Mp), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1,
-                     d.k, d.c, p.ntaps, d.c, Mp, Kp / 16, 0);
+  pack_site_split2(s, w, reinterpret_cast<unsigned*>(ws), inv_a, cells, 1, d.k, d.c, p.ntaps, d.c, Mp, Kp / 16, 0);
   {
     const int nrows = d.n * d.c * Dq * Hq;
     const int pgrid = nrows / 4 < 2048 ? (nrows + 3) / 4 : 2048;
+    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);       // (as above: the pad kernel takes the maximum into the cell)
     hipLaunchKernelGGL(pad_input_kernel, dim3(pgrid), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph, d.pw);
   }
   Geom g;
@@ -1207,10 +1284,14 @@ static void run_k1t(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const int ntiles = d.n * g.ndt * g.nwt;
   unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
-  hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nmblk * bm), dim3(256), 0, s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1,
-                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0, 3);
+  pack_site_patch(s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1, d.k, d.c, g.ncb, bm, nmblk * bm, dgrad ? 1 : 0, 3);
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
-  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  if (src_absmax == nullptr) {
+    // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
+    //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
+    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  }
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
   const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr, st ? st->groups : 1);
   dim3 grid((unsigned)(8 * slots), 1, 1);
@@ -1268,10 +1349,14 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   const int ntiles = (int)((P + KP_NPOS - 1) / KP_NPOS);
   unsigned* cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + main_bytes);
   float* inv_a = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + main_bytes + 256);
-  hipLaunchKernelGGL(pack_weights_patch_kernel, dim3(nmblk * bm), dim3(256), 0, s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1,
-                     d.k, d.c, g.ncb, bm, dgrad ? 1 : 0, 9);
+  pack_site_patch(s, w, reinterpret_cast<uint4*>(ws), inv_a, cells, 1, d.k, d.c, g.ncb, bm, nmblk * bm, dgrad ? 1 : 0, 9);
   const size_t src_elems = (size_t)d.n * g.Cs * d.d * d.h * d.w;
-  if (src_absmax == nullptr) hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  if (src_absmax == nullptr) {
+    // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
+    //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
+    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
+  }
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
   const int slots = k1p_grid_slots(d, g.M, tl.mt, nullptr, nullptr, st ? st->groups : 1);
   dim3 grid((unsigned)(8 * slots), 1, 1);
@@ -1526,8 +1611,7 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
   const size_t tot = (size_t)p.f_Kp * p.f_Mp;
   const bool f_split = p.f_t.sp && !p.f_straddle;
   if (!f_split)
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp,
-                       p.f_Kp, 0);
+    pack_site_native(s, w, wp, d.k, d.c, p.ntaps, p.f_Cp, p.f_Mp, p.f_Kp, 0);
   Geom g;
   g.Cs = d.c; g.Ds = d.d; g.Hs = d.h; g.Ws = d.w;
   g.Nb = d.n; g.Dp = p.Do; g.Hp = p.Ho; g.Wp = p.Wo;
@@ -1579,9 +1663,7 @@ extern "C" int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc*
   }
   const size_t tot = (size_t)p.d_Kp * p.d_Mp;
   const bool d_split = p.d_t.sp != 0;
-  if (!d_split)
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_grid(tot)), dim3(256), 0, s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp,
-                       p.d_Kp, 1);
+  if (!d_split) pack_site_native(s, w, wp, d.k, d.c, p.ntaps, p.d_Cp, p.d_Mp, p.d_Kp, 1);
   Geom g;
   g.Cs = d.k; g.Ds = p.Do; g.Hs = p.Ho; g.Ws = p.Wo;     // gather from dy
   g.Nb = d.n; g.Dp = d.d; g.Hp = d.h; g.Wp = d.w;         // FULL x dims; classes subsample inside
@@ -1610,6 +1692,29 @@ extern "C" int cstp_conv3d_backward_weight_am(void* stream, const cstp_conv_desc
                                               const cstp_in_affine* in_affine, const float* dy, float* dw, void* ws,
                                               size_t ws_bytes, const uint32_t* x_absmax, const uint32_t* dy_absmax) {
   return cstp_conv3d_backward_weight_acc(stream, desc, x, in_affine, dy, dw, ws, ws_bytes, x_absmax, dy_absmax, 0);
+}
+
+extern "C" int cstp_pack_mode(int32_t mode) {
+  CSTP_REQUIRE(mode >= 0 && mode <= 2, "pack mode: 0 (pack inside the calls), 1 (... and record), 2 (skip: the caller replayed the packs)");
+  tl_pack_mode = mode;
+  return 0;
+}
+
+extern "C" int32_t cstp_pack_recorded(cstp_pack_rec* out, int32_t cap) {
+  const int32_t n = (int32_t)tl_pack_recs.size();
+  if (out != nullptr) {
+    for (int32_t i = 0; i < n && i < cap; ++i) out[i] = tl_pack_recs[i];
+    tl_pack_recs.clear();
+  }
+  return n;
+}
+
+extern "C" int cstp_pack_replay(void* stream, const cstp_pack_rec* recs_dev, const int32_t* first_block_dev, int32_t n,
+                                int32_t total_blocks) {
+  CSTP_REQUIRE(recs_dev && first_block_dev && n > 0 && total_blocks > 0, "bad argument");
+  hipLaunchKernelGGL(pack_replay_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), recs_dev, first_block_dev, n);
+  CSTP_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int cstp_set_deterministic(int32_t on) {

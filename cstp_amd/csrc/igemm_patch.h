@@ -73,12 +73,13 @@ struct PGeom {
 // two (inv_a[m] = its inverse); logical chunk L = 4 * plane + (k % 32) / 8 sits at L ^ (row & 7).  One block per row m.
 // forward: value(m, c, tap) = w[m][c][tap];  data gradient: rows are INPUT channels, k runs over OUTPUT channels and the
 // taps are mirrored: value(m = c_in, c = k_out, tap) = w[k_out][c_in][8 - tap].
-__global__ void __launch_bounds__(256)
-pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, float* __restrict__ inv_a,
-                          unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad,
-                          int nt) {       // nt: filter taps (9: igemm_k1p; 3: the temporal layers' igemm_k1t)
+__device__ __forceinline__ void
+pack_patch_body(const float* __restrict__ w, uint4* __restrict__ wpk, float* __restrict__ inv_a,
+                unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad,
+                int nt, const int m_in) {    // nt: filter taps (9: igemm_k1p; 3: the temporal layers' igemm_k1t); m: the block's row
   __shared__ unsigned red[4];
-  const int m = blockIdx.x, t = threadIdx.x;
+  const int m = __builtin_amdgcn_readfirstlane(m_in);
+  const int t = threadIdx.x;
   if (m == 0 && t < ncells) cells[t] = 0;
   const int mreal = dgrad ? cin : kout, creal = dgrad ? kout : cin;
   auto fetch = [&](int c, int tap) __attribute__((always_inline)) -> float {
@@ -119,6 +120,12 @@ pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, 
     row[c8 ^ (rloc & 7)] = ph;
     row[(4 + c8) ^ (rloc & 7)] = pl;
   }
+}
+__global__ void __launch_bounds__(256)
+pack_weights_patch_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, float* __restrict__ inv_a,
+                          unsigned* __restrict__ cells, int ncells, int kout, int cin, int ncb, int rows_per_blk, int dgrad,
+                          int nt) {
+  pack_patch_body(w, wpk, inv_a, cells, ncells, kout, cin, ncb, rows_per_blk, dgrad, nt, (int)blockIdx.x);
 }
 
 // STATS: the forward launch also leaves, per output channel and BatchNorm group, the sums of the outputs and of their squares

@@ -176,12 +176,16 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned 
 // 2xf16 split weights: wps[group = k/16][m (Mp)][plane (2)][k%16] f16 with row m scaled by a power of two (inv_a[m] = its
 // inverse); one block per row m: largest magnitude of the row, then split and store.  Block 0 also zeroes the `ncells`
 // absmax cells of the activation operand(s), which the kernels launched next fill.
-__global__ void __launch_bounds__(256)
-pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ wps, float* __restrict__ inv_a,
-                           unsigned* __restrict__ cells, int ncells, int kout, int cin, int ntaps, int Cp, int Mp, int ngroups,
-                           int dgrad) {
+// (the body is a device function of the block's row m: pack_replay_kernel -- igemm.hip -- runs the packs of a whole network pass
+//  from ONE launch with it)
+template <int PAIRS>      // pairs of the row a thread keeps in registers between the maximum and the split (0: fetch twice -- the replay kernel)
+__device__ __forceinline__ void
+pack_split2_body(const float* __restrict__ w, unsigned* __restrict__ wps, float* __restrict__ inv_a,
+                 unsigned* __restrict__ cells, int ncells, int kout, int cin, int ntaps, int Cp, int Mp, int ngroups,
+                 int dgrad, const int m_in) {
   __shared__ unsigned red[4];
-  const int m = blockIdx.x, t = threadIdx.x;
+  const int m = __builtin_amdgcn_readfirstlane(m_in);      // (the row is block-uniform: keeps the row's address arithmetic scalar)
+  const int t = threadIdx.x;
   if (m == 0 && t < ncells) cells[t] = 0;
   const int mreal = dgrad ? cin : kout, creal = dgrad ? kout : cin;
   auto fetch = [&](int k) __attribute__((always_inline)) -> float {
@@ -191,9 +195,8 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
   };
   // one pass over the row: thread t owns the k-pairs t, t + 256, ... and keeps up to PAIRS of them in registers between the
   // maximum and the split (longer rows -- K > 512 * PAIRS -- fetch the tail a second time)
-  constexpr int PAIRS = 24;
   const int npairs = ngroups * 8;
-  float v0[PAIRS], v1[PAIRS];
+  float v0[PAIRS > 0 ? PAIRS : 1], v1[PAIRS > 0 ? PAIRS : 1];
   unsigned mx = 0;
 #pragma unroll
   for (int i = 0; i < PAIRS; ++i) {
@@ -231,6 +234,12 @@ pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ w
     if (pi < npairs) put(pi, v0[i], v1[i]);
   }
   for (int pi = t + 256 * PAIRS; pi < npairs; pi += 256) put(pi, fetch(2 * pi), fetch(2 * pi + 1));
+}
+__global__ void __launch_bounds__(256)
+pack_weights_split2_kernel(const float* __restrict__ w, unsigned* __restrict__ wps, float* __restrict__ inv_a,
+                           unsigned* __restrict__ cells, int ncells, int kout, int cin, int ntaps, int Cp, int Mp, int ngroups,
+                           int dgrad) {
+  pack_split2_body<24>(w, wps, inv_a, cells, ncells, kout, cin, ntaps, Cp, Mp, ngroups, dgrad, (int)blockIdx.x);
 }
 
 // NH = 128-column halves per block tile (1 or 2).  NH = 2 (256 positions per block) halves the weight-operand traffic per

@@ -66,6 +66,123 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+class PackPlan:
+    """The weight packs of a training step from THREE launches instead of ~137 (include/cstp_hip.h: cstp_pack_*).
+
+    Every convolution / linear call re-lays its weights out for its kernel variant (~10 us per call on the step's critical
+    chain: 1.3 ms of a 54 ms R(2+1)D-18 step, profiles/r04).  Inside a training step the weights change at exactly two points --
+    the optimizer step (online network, predictor, heads) and the EMA (target network) -- so the step that owns the model
+    (PretrainStep) hoists the packs: each (weight, direction) call site gets a PERSISTENT workspace; one step RECORDS the pack
+    launches of every call (state "record"); from then on ``replay("online")`` at the top of a step and ``replay("target")``
+    right behind the EMA run all recorded packs of that group from one launch each, and the calls skip theirs.  Outside an
+    armed step (validation, fine-tuning, tests that call the model directly) nothing changes: calls pack for themselves.
+    A call whose (weight, tag, descriptor) was not recorded packs for itself too."""
+
+    def __init__(self, target_range=None):
+        self.state = "off"            # "off" | "record" | "replay"
+        self.armed = False            # True only inside the owning step
+        self.ws = {}                  # key -> persistent workspace
+        self.recs = {}                # key -> [PackRec, ...] (what that call packs)
+        self.tables = {}              # group -> (recs_dev, first_dev, n, total_blocks)
+        self.target_range = target_range      # (ptr_lo, ptr_hi) of the EMA target arena: its packs replay behind the EMA
+        self.stats = {"replays": 0, "skipped_calls": 0, "recorded_calls": 0}
+
+    @staticmethod
+    def key(w_param, tag, desc):
+        return (w_param.data_ptr(), tag) + _desc_key(desc)
+
+    def workspace(self, key, device, nbytes):
+        ws = self.ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if ws is not None and self.state == "replay":
+                self.invalidate()             # a recorded buffer is being replaced: the device tables point at the old one
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self.ws[key] = ws
+            self.recs.pop(key, None)          # a new buffer: whatever was recorded for the old one is void
+        return ws
+
+    def call(self, key, fn):
+        """Run the C-ABI call ``fn`` under the pack mode this key is in."""
+        lib = _lib.load()
+        if self.state == "record":
+            lib.cstp_pack_mode(1)
+            try:
+                fn()
+            finally:
+                lib.cstp_pack_mode(0)
+                n = lib.cstp_pack_recorded(None, 0)
+                buf = (_lib.PackRec * max(n, 1))()
+                lib.cstp_pack_recorded(buf, n)
+            self.recs[key] = [buf[i] for i in range(n)]
+            self.stats["recorded_calls"] += 1
+        elif self.state == "replay" and key in self.recs:
+            lib.cstp_pack_mode(2)
+            try:
+                fn()
+            finally:
+                lib.cstp_pack_mode(0)
+            self.stats["skipped_calls"] += 1
+        else:
+            fn()
+
+    def finish_record(self, device):
+        """Build the per-group device tables from what the recording step collected."""
+        groups = {"online": [], "target": []}
+        lo, hi = self.target_range if self.target_range is not None else (0, 0)
+        for key, recs in self.recs.items():
+            for r in recs:
+                groups["target" if (lo <= (r.w or 0) < hi) else "online"].append(r)
+        self.tables = {}
+        for name, recs in groups.items():
+            if not recs:
+                continue
+            arr = (_lib.PackRec * len(recs))(*recs)
+            first, tot = [], 0
+            for r in recs:
+                first.append(tot)
+                tot += int(r.nblocks)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self.tables[name] = (raw.to(device), torch.tensor(first, dtype=torch.int32, device=device), len(recs), tot)
+        self.state = "replay"
+
+    def invalidate(self):
+        """The kernels a recorded call would run may have changed (arithmetic, deterministic mode, a pinned tile): forget the
+        records; the owning step records again after two quiet steps."""
+        self.state, self.recs, self.tables, self.quiet = "off", {}, {}, 0
+
+    def tick(self):
+        """Start of an owning step: after two steps without a change of kernels the next one records."""
+        if self.state == "off":
+            self.quiet = getattr(self, "quiet", 0) + 1
+            if self.quiet > 2:
+                self.state = "record"
+
+    def replay(self, group):
+        if self.state != "replay" or not self.armed:
+            return
+        t = self.tables.get(group)
+        if t is None:
+            return
+        check(_lib.load().cstp_pack_replay(_stream(), t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]), "cstp_pack_replay")
+        self.stats["replays"] += 1
+
+
+pack_plan: Optional[PackPlan] = None          # set by the training step that owns the model (train.PretrainStep)
+
+
+def _packed_call(w_param, tag, desc, device, nbytes, fn):
+    """``fn(ws)`` = one C-ABI convolution call that packs ``w_param`` into its workspace: through the pack plan when a
+    training step has armed one (persistent workspace, recorded / skipped pack), else on the shared scratch arena."""
+    plan = pack_plan
+    if plan is None or not plan.armed or plan.state == "off" or w_param is None:
+        ws = _workspace(device, nbytes)
+        fn(ws)
+        return
+    key = PackPlan.key(w_param, tag, desc)
+    ws = plan.workspace(key, device, nbytes)
+    plan.call(key, lambda: fn(ws))
+
+
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.CstpError("%s must be on a HIP device (cstp_amd has no CPU path)" % name)
@@ -186,6 +303,8 @@ def _autotune(lib, desc, mode, src, w, out, ws):
     if key in _tuned:
         return
     _tuned.add(key)
+    if pack_plan is not None:
+        pack_plan.invalidate()       # a layer gets its tile now: recorded packs may belong to another variant
     tbl = _load_table()
     sk = _table_key(arith, mode, desc)
     tile = tbl.get(sk)
@@ -234,12 +353,16 @@ def share_tune_table(src: int = 0) -> None:
             continue
         desc = ConvDesc(*[int(v) for v in fields.split(",")])
         lib.cstp_conv3d_set_tile(ctypes.byref(desc), int(mode), (ctypes.c_int32 * 4)(*tile))
+        if pack_plan is not None:
+            pack_plan.invalidate()
 
 
 def set_split_terms(terms: int) -> None:
     """2 = f16 pair / three MFMA products (default), 3 = bf16 triple / six products, 1 = native f32 MFMA only,
     0 = environment default (cstp_gemm_set_split_terms).  Each arithmetic has its own class of tuned tiles."""
     check(_lib.load().cstp_gemm_set_split_terms(int(terms)), "cstp_gemm_set_split_terms")
+    if pack_plan is not None:
+        pack_plan.invalidate()
 
 
 def set_deterministic(on: bool) -> None:
@@ -247,6 +370,9 @@ def set_deterministic(on: bool) -> None:
     the first convolution call of a run: the shared workspace is sized by what the library reports at that time."""
     check(_lib.load().cstp_set_deterministic(1 if on else 0), "cstp_set_deterministic")
     _ws_cache.clear()
+    if pack_plan is not None:
+        pack_plan.invalidate()
+        pack_plan.ws.clear()
 
 
 def set_conv_tile(x_shape, w_shape, stride, padding, mode: int, tile) -> None:
@@ -256,6 +382,8 @@ def set_conv_tile(x_shape, w_shape, stride, padding, mode: int, tile) -> None:
     desc = _desc(tuple(x_shape), tuple(w_shape), _triple(stride), _triple(padding))
     arr = (ctypes.c_int32 * 4)(*[int(v) for v in tile])
     check(lib.cstp_conv3d_set_tile(ctypes.byref(desc), int(mode), arr), "cstp_conv3d_set_tile")
+    if pack_plan is not None:
+        pack_plan.invalidate()
     _tuned.add((lib.cstp_gemm_get_split_terms(), int(mode)) + tuple(getattr(desc, f) for f, _ in ConvDesc._fields_))
 
 
@@ -422,7 +550,8 @@ class _Conv3d(torch.autograd.Function):
         # statistics' partial sums beside y (cstp_conv3d_forward_bnstats) and batch_norm_act skips its pass over the tensor
         ns = lib.cstp_conv3d_bnstats_nsplit(ctypes.byref(desc), bn_groups) if (bn_groups > 0 and b is None and FUSE_BN_STATS) else 0
         _Conv3d._last_stats = None
-        with _span("conv3d_forward", lambda: _desc_key(desc)):
+
+        def run(ws):
             if ns > 0:
                 # sums [k][groups][ns][2], pivots [k], then the (min, max) keys [k][groups][ns][2] as uint32 (one double each)
                 part = torch.empty(w.shape[0] * bn_groups * ns * 3 + w.shape[0], dtype=torch.float64, device=x.device)
@@ -440,6 +569,9 @@ class _Conv3d(torch.autograd.Function):
             else:
                 check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), _ptr(b), None,
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
+
+        with _span("conv3d_forward", lambda: _desc_key(desc)):
+            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "f", desc, x.device, nbytes, run)
         ctx.save_for_backward(x, w)
         ctx.w_param = w_in           # the parameter object itself (save_for_backward hands back a new tensor object)
         ctx.grad_join = grad_join
@@ -487,15 +619,15 @@ class _Conv3d(torch.autograd.Function):
                 if cell is not None:
                     cell.record_stream(side)
             _queue_join(x.device)
-        ws = _workspace(x.device, nbytes)
         if ctx.needs_input_grad[0]:
             def dgrad(dst, acc):
                 if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
-                    _autotune(lib, desc, 1, dy, w, torch.empty_like(dst) if acc else dst, ws)   # (tuning overwrites its output)
+                    _autotune(lib, desc, 1, dy, w, torch.empty_like(dst) if acc else dst, _workspace(x.device, nbytes))   # (tuning overwrites its output)
                 with _span("conv3d_backward_data", lambda: _desc_key(desc)):
-                    check(lib.cstp_conv3d_backward_data_acc(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
-                                                            dst.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(dyam), 1 if acc else 0),
-                          "cstp_conv3d_backward_data")
+                    _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", desc, x.device, nbytes,
+                                 lambda ws: check(lib.cstp_conv3d_backward_data_acc(
+                                     _stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dst.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), _ptr(dyam), 1 if acc else 0), "cstp_conv3d_backward_data"))
                 return dst
             join = ctx.grad_join
             if join is None:
@@ -506,6 +638,7 @@ class _Conv3d(torch.autograd.Function):
             wgrad_into_arena()
         elif ctx.needs_input_grad[1] and not direct_w:
             dw = torch.empty_like(w)
+            ws = _workspace(x.device, nbytes)
             if AUTOTUNE:
                 _autotune(lib, desc, 2, x, dy, dw, ws)
             with _span("conv3d_backward_weight", lambda: _desc_key(desc)):
@@ -743,7 +876,8 @@ class _BNReluConv3d(torch.autograd.Function):
         # sums and range beside y (the temporal patch kernel igemm_k1t<.., STATS, AFF>)
         ns = lib.cstp_conv3d_bnstats_nsplit_aff(ctypes.byref(desc), out_groups) if (out_groups > 0 and FUSE_BN_STATS) else 0
         _BNReluConv3d._last_stats = None
-        with _span("conv3d_forward", lambda: _desc_key(desc)):
+
+        def run(ws):
             if ns > 0:
                 part = torch.empty(w.shape[0] * out_groups * ns * 3 + w.shape[0], dtype=torch.float64, device=x.device)
                 ycell = torch.empty(1, dtype=torch.int32, device=x.device)
@@ -758,6 +892,11 @@ class _BNReluConv3d(torch.autograd.Function):
             else:
                 check(lib.cstp_conv3d_forward_am(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), None, ctypes.byref(aff),
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(zam)), "cstp_conv3d_forward")
+
+        with _span("conv3d_forward", lambda: _desc_key(desc)):
+            # ("fa": a forward that carries the in_affine may run another kernel variant -- another pack -- than the plain one)
+            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "fa", desc, x.device,
+                         lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), run)
         ctx.save_for_backward(x, gamma, mean, invstd, ss, w)
         ctx.desc, ctx.groups, ctx.relu, ctx.z_absmax = desc, groups, relu, zam
         ctx.params = (g_in, b_in, w_in)      # the parameter objects themselves (their .grad may be an arena slice)
@@ -810,8 +949,11 @@ class _BNReluConv3d(torch.autograd.Function):
             if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
                 _autotune(lib, desc, 1, dy, w, dz, ws)
             with _span("conv3d_backward_data", lambda: _desc_key(desc)):
-                check(lib.cstp_conv3d_backward_data_acc(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(),
-                                                        ws.data_ptr(), ws.numel(), _ptr(dyam), 0), "cstp_conv3d_backward_data")
+                _packed_call(pw if w.data_ptr() == pw.data_ptr() else None, "d", desc, x.device,
+                             lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)),
+                             lambda wsd: check(lib.cstp_conv3d_backward_data_acc(
+                                 _stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(), wsd.data_ptr(),
+                                 wsd.numel(), _ptr(dyam), 0), "cstp_conv3d_backward_data"))
             dx = torch.empty_like(x)
             direct = ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _direct(pg) and _direct(pb)
             dgamma = pg.grad if direct else torch.empty_like(gamma)

@@ -527,6 +527,8 @@ class ByolBase(nn.Module):
         if self._arenas is not None:
             a = self._arenas
             ops.ema_update_(a["target"], a["param"][:a["n_encoder"]], self.momentum)
+            if ops.pack_plan is not None:
+                ops.pack_plan.replay("target")          # the target network's weight packs of this step: one launch behind the EMA
         else:
             for pq, pk in zip(self.online_net.parameters(), self.target_net.parameters()):
                 ops.ema_update_(pk.data, pq.data, self.momentum)

@@ -222,6 +222,13 @@ class PretrainStep:
         self._direct = arenas is not None and (self._flat_grad is not None or not hasattr(model, "no_sync"))
         ops.mark_direct_grad(self._inner, arenas, self._direct)
         self._tiles_shared = False
+        # the weight packs of a step from three launches (ops.PackPlan): models whose parameters live in the flat arenas on a HIP
+        # device; CSTP_PACK_PLAN=0 keeps the per-call packs
+        self._packs = None
+        if arenas is not None and arenas["param"].is_cuda and os.environ.get("CSTP_PACK_PLAN", "1") != "0":
+            tgt = arenas.get("target")
+            rng = (tgt.data_ptr(), tgt.data_ptr() + tgt.numel() * tgt.element_size()) if tgt is not None else None
+            self._packs = ops.PackPlan(rng)
 
     def __call__(self, clip_1, clip_2, spa, tem, pb, rot_1, rot_2) -> StepOutput:
         if self._flat_grad is not None:
@@ -229,13 +236,26 @@ class PretrainStep:
         sync_ctx = self.model.no_sync() if self._flat_grad is not None else contextlib.nullcontext()
         if self._reducer is not None:
             self._reducer.begin()
+        plan = self._packs
+        if plan is not None:
+            ops.pack_plan = plan
+            plan.tick()
+            plan.armed = True
+            plan.replay("online")          # every online / predictor / head weight pack of this step: one launch
         try:
             with sync_ctx:
                 out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
         except BaseException:
             if self._reducer is not None:
                 self._reducer.abort()
+            if plan is not None:
+                plan.armed = False
+                plan.invalidate()
             raise
+        if plan is not None:
+            if plan.state == "record":
+                plan.finish_record(clip_1.device)
+            plan.armed = False
         if self._reducer is not None:
             self._reducer.finish()
         gnorm = self.optimizer.clip_grad_norm_(CLIP_VALUE) if self.clip else None

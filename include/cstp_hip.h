@@ -151,6 +151,29 @@ int32_t cstp_get_deterministic(void);
 int cstp_gemm_set_split_terms(int32_t terms);
 int32_t cstp_gemm_get_split_terms(void);
 
+/* The weight packs of a whole network pass from ONE launch.  Every convolution / linear call re-lays its weights out for the
+ * kernel variant it runs (a launch of ~10 us per call: ~137 per R(2+1)D-18 training step, main_byol.py:60-91 being ONE Python
+ * step).  A caller that keeps a PERSISTENT workspace per (weight tensor, direction) can hoist them:
+ *   cstp_pack_mode(1); <the call>; cstp_pack_mode(0);  n = cstp_pack_recorded(recs, cap);     -- once: what the call packs
+ *   cstp_pack_replay(stream, recs_dev, first_block_dev, n, total_blocks);                     -- per pass: all recorded packs
+ *   cstp_pack_mode(2); <the same call, same pointers>; cstp_pack_mode(0);                     -- the call skips its pack
+ * A record is the pack launch itself (kind 1: f16-pair split rows, 2: LDS-patch K-tiles, 3: native fp32 re-layout; pointers,
+ * integer arguments, blocks of 256 threads), so the replay does exactly what the call would have done -- provided descriptor,
+ * tile table, weight pointer and workspace pointer are those of the recorded call.  first_block_dev[i] = sum of nblocks of the
+ * records before i; total_blocks = the sum over all.  The mode is per calling THREAD (0 = default).  bf16-triple packs and the
+ * bf16-storage path are not recorded (they keep packing inside the call in every mode). */
+typedef struct cstp_pack_rec {
+  int32_t kind, nblocks;
+  const float* w;
+  void* dst;
+  float* inv_a;
+  uint32_t* cells;
+  int32_t a[10];
+} cstp_pack_rec;
+int cstp_pack_mode(int32_t mode);
+int32_t cstp_pack_recorded(cstp_pack_rec* out, int32_t cap);
+int cstp_pack_replay(void* stream, const cstp_pack_rec* recs_dev, const int32_t* first_block_dev, int32_t n, int32_t total_blocks);
+
 /* Which kernel variant the next forward (mode 0) / backward_data (mode 1) / backward_weight (mode 2) call with this
  * descriptor will run: out[0] = rows per block tile, out[1] = positions (mode 2: (tap, channel) columns) per block tile,
  * out[2] = 0 for the native f32 MFMA kernel, else the number of terms each operand is split into by the split kernel (2 or

@@ -356,3 +356,45 @@ def test_three_gemm_arithmetics_against_the_fp64_truth_on_a_full_backward():
         assert dl < 1e-5 and dlog < 1e-4, (name, report)
     worst_native = max(report["native f32"][2], 1e-3)
     assert report["bf16 triple"][2] < 3 * worst_native and report["f16 pair"][2] < 3 * worst_native, report
+
+
+def test_pack_plan_steps_are_bit_identical_to_steps_that_pack_inside_every_call(monkeypatch):
+    """ops.PackPlan (the weight packs of a step from three launches: one for the online network, predictor and heads at the
+    top of the step, one for the target network behind the EMA) against the per-call packs: seven steps of the same model on
+    the same clips in deterministic mode must leave bit-identical parameters, momenta, targets and running statistics --
+    and the plan must actually have recorded and replayed."""
+    from cstp_amd import ops
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.synthetic import device_batch
+    from cstp_amd.train import PretrainStep
+    ops.set_deterministic(True)
+    try:
+        dev = torch.device("cuda", 0)
+        x1, x2, lab = device_batch(2, 8, 56, dev, seed=3)
+        finals = []
+        for plan_on in ("1", "0"):
+            monkeypatch.setenv("CSTP_PACK_PLAN", plan_on)
+            torch.manual_seed(5)
+            model = build_model((1, 1, 1, 1))
+            opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=model._arenas)
+            step = PretrainStep(model, opt, (0.1, 1.0, 1.0, 1.0, 1.0), clip_grad_norm=True)
+            assert (step._packs is not None) == (plan_on == "1")
+            losses = []
+            for _ in range(7):
+                out = step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+                losses.append(float(out.loss_total))
+            torch.cuda.synchronize()
+            if plan_on == "1":
+                st = step._packs.stats
+                assert step._packs.state == "replay" and st["recorded_calls"] > 50, st
+                assert st["replays"] >= 2 * 3 and st["skipped_calls"] >= 3 * st["recorded_calls"] - 5, st
+            finals.append((losses, {k: v.clone() for k, v in model.state_dict().items()},
+                           [s["momentum_buffer"].clone() for s in opt.state_dict()["state"].values()]))
+        (la, sa, ma), (lb, sb, mb) = finals
+        assert la == lb
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+        assert len(ma) == len(mb) and all(torch.equal(a, b) for a, b in zip(ma, mb))
+    finally:
+        ops.set_deterministic(False)
+        ops.pack_plan = None
