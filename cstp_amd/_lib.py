@@ -56,6 +56,7 @@ SIGNATURES = {
     "cstp_pack_mode": (c_int32, [c_int32]),
     "cstp_pack_recorded": (c_int32, [POINTER(PackRec), c_int32]),
     "cstp_pack_replay": (c_int32, [_P, _P, _P, c_int32, c_int32]),
+    "cstp_pack_register": (c_int32, [POINTER(c_void_p), c_int32, c_int32]),
     "cstp_set_deterministic": (c_int32, [c_int32]),
     "cstp_get_deterministic": (c_int32, []),
     "cstp_gemm_set_split_terms": (c_int32, [c_int32]),

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "common.h"
@@ -1092,10 +1093,22 @@ static int pack_grid(size_t total) {
 // variant the dispatch picked is what gets replayed.
 static thread_local int tl_pack_mode = 0;
 static thread_local std::vector<cstp_pack_rec> tl_pack_recs;
+// ... and, without any per-call mode switch: workspaces the caller REGISTERED as holding replayed packs (cstp_pack_register) are
+// never packed into by the calls that receive them (process-wide, mutex-guarded; a relaxed counter keeps the common empty case
+// lock-free)
+static std::mutex g_prepacked_mu;
+static std::unordered_set<const void*> g_prepacked;
+static std::atomic<int> g_prepacked_n{0};
+static bool pack_skip(const void* dst) {
+  if (tl_pack_mode == 2) return true;
+  if (tl_pack_mode == 1 || g_prepacked_n.load(std::memory_order_relaxed) == 0) return false;
+  std::lock_guard<std::mutex> lk(g_prepacked_mu);
+  return g_prepacked.count(dst) != 0;
+}
 
 static void pack_site_split2(hipStream_t s, const float* w, unsigned* wps, float* inv_a, unsigned* cells, int ncells, int kout,
                              int cin, int ntaps, int Cp, int Mp, int ngroups, int dgrad) {
-  if (tl_pack_mode == 2) return;
+  if (pack_skip(wps)) return;
   if (tl_pack_mode == 1) {
     cstp_pack_rec r{};
     r.kind = 1; r.nblocks = Mp; r.w = w; r.dst = wps; r.inv_a = inv_a; r.cells = cells;
@@ -1108,7 +1121,7 @@ static void pack_site_split2(hipStream_t s, const float* w, unsigned* wps, float
 }
 static void pack_site_patch(hipStream_t s, const float* w, uint4* wpk, float* inv_a, unsigned* cells, int ncells, int kout, int cin,
                             int ncb, int rows_per_blk, int nblk_rows, int dgrad, int nt) {
-  if (tl_pack_mode == 2) return;
+  if (pack_skip(wpk)) return;
   if (tl_pack_mode == 1) {
     cstp_pack_rec r{};
     r.kind = 2; r.nblocks = nblk_rows; r.w = w; r.dst = wpk; r.inv_a = inv_a; r.cells = cells;
@@ -1120,7 +1133,7 @@ static void pack_site_patch(hipStream_t s, const float* w, uint4* wpk, float* in
                      rows_per_blk, dgrad, nt);
 }
 static void pack_site_native(hipStream_t s, const float* w, float* wp, int kout, int cin, int ntaps, int Cp, int Mp, int Kp, int dgrad) {
-  if (tl_pack_mode == 2) return;
+  if (pack_skip(wp)) return;
   const int nb = pack_grid((size_t)Kp * Mp);
   if (tl_pack_mode == 1) {
     cstp_pack_rec r{};
@@ -1145,7 +1158,7 @@ pack_replay_kernel(const cstp_pack_rec* __restrict__ recs, const int* __restrict
   const int lb = b - first[lo];
   const int* a = R.a;
   if (R.kind == 1)
-    pack_split2_body<0>(R.w, reinterpret_cast<unsigned*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lb);
+    pack_split2_body<8>(R.w, reinterpret_cast<unsigned*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lb);
   else if (R.kind == 2)
     pack_patch_body(R.w, reinterpret_cast<uint4*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], lb);
   else
@@ -1209,7 +1222,7 @@ static void run_k1s(const Tile& tl, dim3 grid, hipStream_t s, const Geom& g, con
   if (src_absmax == nullptr) {
     // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
     //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
-    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    if (pack_skip(ws)) (void)hipMemsetAsync(cells, 0, 8, s);
     hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   }
   launch_k1s_np<DGRAD, 2>(tl, grid, s, g, reinterpret_cast<const uint4*>(ws), src, bias, out, ntx, ntm, inv_a,
@@ -1231,7 +1244,7 @@ static void run_k1s_stem(const Tile& tl, hipStream_t s, const cstp_conv_desc& d,
   {
     const int nrows = d.n * d.c * Dq * Hq;
     const int pgrid = nrows / 4 < 2048 ? (nrows + 3) / 4 : 2048;
-    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);       // (as above: the pad kernel takes the maximum into the cell)
+    if (pack_skip(ws)) (void)hipMemsetAsync(cells, 0, 8, s);       // (as above: the pad kernel takes the maximum into the cell)
     hipLaunchKernelGGL(pad_input_kernel, dim3(pgrid), dim3(256), 0, s, x, xp, cells, d.n * d.c, d.d, d.h, d.w, d.pt, d.ph, d.pw);
   }
   Geom g;
@@ -1289,7 +1302,7 @@ static void run_k1t(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   if (src_absmax == nullptr) {
     // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
     //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
-    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    if (pack_skip(ws)) (void)hipMemsetAsync(cells, 0, 8, s);
     hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   }
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
@@ -1354,7 +1367,7 @@ static void run_k1p(const Tile& tl, hipStream_t s, const cstp_conv_desc& d, bool
   if (src_absmax == nullptr) {
     // (the pack kernel zeroes the cells; when the caller replayed the packs -- possibly once for several calls on this
     //  workspace -- the cell is zeroed here, so that it holds THIS call's operand maximum exactly)
-    if (tl_pack_mode == 2) (void)hipMemsetAsync(cells, 0, 8, s);
+    if (pack_skip(ws)) (void)hipMemsetAsync(cells, 0, 8, s);
     hipLaunchKernelGGL(absmax_kernel, dim3(absmax_grid(src_elems)), dim3(256), 0, s, src, src_elems, cells);
   }
   const unsigned* bcell = src_absmax != nullptr ? src_absmax : cells;
@@ -1707,6 +1720,17 @@ extern "C" int32_t cstp_pack_recorded(cstp_pack_rec* out, int32_t cap) {
     tl_pack_recs.clear();
   }
   return n;
+}
+
+extern "C" int cstp_pack_register(const void* const* workspaces, int32_t n, int32_t on) {
+  CSTP_REQUIRE(n >= 0 && (n == 0 || workspaces != nullptr), "bad argument");
+  std::lock_guard<std::mutex> lk(g_prepacked_mu);
+  if (n == 0 && !on) g_prepacked.clear();
+  for (int32_t i = 0; i < n; ++i) {
+    if (on) g_prepacked.insert(workspaces[i]); else g_prepacked.erase(workspaces[i]);
+  }
+  g_prepacked_n.store((int)g_prepacked.size(), std::memory_order_relaxed);
+  return 0;
 }
 
 extern "C" int cstp_pack_replay(void* stream, const cstp_pack_rec* recs_dev, const int32_t* first_block_dev, int32_t n,

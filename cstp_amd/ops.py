@@ -88,8 +88,8 @@ class PackPlan:
         self.stats = {"replays": 0, "skipped_calls": 0, "recorded_calls": 0}
 
     @staticmethod
-    def key(w_param, tag, desc):
-        return (w_param.data_ptr(), tag) + _desc_key(desc)
+    def key(w_param, tag, x_shape):
+        return (w_param.data_ptr(), tag, tuple(x_shape))      # (a weight tensor fixes kernel size, stride and padding)
 
     def workspace(self, key, device, nbytes):
         ws = self.ws.get(key)
@@ -115,23 +115,26 @@ class PackPlan:
                 lib.cstp_pack_recorded(buf, n)
             self.recs[key] = [buf[i] for i in range(n)]
             self.stats["recorded_calls"] += 1
-        elif self.state == "replay" and key in self.recs:
-            lib.cstp_pack_mode(2)
-            try:
-                fn()
-            finally:
-                lib.cstp_pack_mode(0)
-            self.stats["skipped_calls"] += 1
         else:
+            # (replay state: the call's workspace is REGISTERED with the library -- cstp_pack_register -- so the call skips its pack
+            #  without any per-call switch; the host spends one dictionary lookup here)
             fn()
+            if self.state == "replay" and key in self.recs:
+                self.stats["skipped_calls"] += 1
 
     def finish_record(self, device):
         """Build the per-group device tables from what the recording step collected."""
-        groups = {"online": [], "target": []}
+        # three groups: the target network's packs (replayed behind the EMA), the online / predictor / head FORWARD packs (top of
+        # the step, main stream) and their DATA-GRADIENT packs (mirrored taps, gathered across the output channels: the expensive
+        # ones -- top of the step too, but on the side stream: nothing needs them before the backward pass)
+        groups = {"online": [], "online_d": [], "target": []}
         lo, hi = self.target_range if self.target_range is not None else (0, 0)
         for key, recs in self.recs.items():
             for r in recs:
-                groups["target" if (lo <= (r.w or 0) < hi) else "online"].append(r)
+                if lo <= (r.w or 0) < hi:
+                    groups["target"].append(r)
+                else:
+                    groups["online_d" if key[1] == "d" else "online"].append(r)
         self.tables = {}
         for name, recs in groups.items():
             if not recs:
@@ -143,12 +146,30 @@ class PackPlan:
                 tot += int(r.nblocks)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             self.tables[name] = (raw.to(device), torch.tensor(first, dtype=torch.int32, device=device), len(recs), tot)
+        dsts = sorted({int(r.dst) for recs in groups.values() for r in recs if r.dst})
+        if dsts:
+            arr = (ctypes.c_void_p * len(dsts))(*dsts)
+            check(_lib.load().cstp_pack_register(arr, len(dsts), 1), "cstp_pack_register")
+        self._registered = dsts
         self.state = "replay"
 
     def invalidate(self):
         """The kernels a recorded call would run may have changed (arithmetic, deterministic mode, a pinned tile): forget the
         records; the owning step records again after two quiet steps."""
+        dsts = getattr(self, "_registered", None)
+        if dsts:
+            arr = (ctypes.c_void_p * len(dsts))(*dsts)
+            _lib.load().cstp_pack_register(arr, len(dsts), 0)
+        self._registered = []
         self.state, self.recs, self.tables, self.quiet = "off", {}, {}, 0
+
+    def __del__(self):
+        # the library must forget this plan's workspaces before their memory is reused (a registered address that became someone
+        # else's scratch buffer would make that call skip its pack)
+        try:
+            self.invalidate()
+        except Exception:       # interpreter shutdown
+            pass
 
     def tick(self):
         """Start of an owning step: after two steps without a change of kernels the next one records."""
@@ -170,7 +191,7 @@ class PackPlan:
 pack_plan: Optional[PackPlan] = None          # set by the training step that owns the model (train.PretrainStep)
 
 
-def _packed_call(w_param, tag, desc, device, nbytes, fn):
+def _packed_call(w_param, tag, x_shape, device, nbytes, fn):
     """``fn(ws)`` = one C-ABI convolution call that packs ``w_param`` into its workspace: through the pack plan when a
     training step has armed one (persistent workspace, recorded / skipped pack), else on the shared scratch arena."""
     plan = pack_plan
@@ -178,9 +199,14 @@ def _packed_call(w_param, tag, desc, device, nbytes, fn):
         ws = _workspace(device, nbytes)
         fn(ws)
         return
-    key = PackPlan.key(w_param, tag, desc)
+    key = PackPlan.key(w_param, tag, x_shape)
     ws = plan.workspace(key, device, nbytes)
-    plan.call(key, lambda: fn(ws))
+    if plan.state == "record":
+        plan.call(key, lambda: fn(ws))
+    else:
+        fn(ws)
+        if plan.state == "replay" and key in plan.recs:
+            plan.stats["skipped_calls"] += 1
 
 
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -571,7 +597,7 @@ class _Conv3d(torch.autograd.Function):
                                                  y.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(xam)), "cstp_conv3d_forward")
 
         with _span("conv3d_forward", lambda: _desc_key(desc)):
-            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "f", desc, x.device, nbytes, run)
+            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "f", x.shape, x.device, nbytes, run)
         ctx.save_for_backward(x, w)
         ctx.w_param = w_in           # the parameter object itself (save_for_backward hands back a new tensor object)
         ctx.grad_join = grad_join
@@ -624,7 +650,7 @@ class _Conv3d(torch.autograd.Function):
                 if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
                     _autotune(lib, desc, 1, dy, w, torch.empty_like(dst) if acc else dst, _workspace(x.device, nbytes))   # (tuning overwrites its output)
                 with _span("conv3d_backward_data", lambda: _desc_key(desc)):
-                    _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", desc, x.device, nbytes,
+                    _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", x.shape, x.device, nbytes,
                                  lambda ws: check(lib.cstp_conv3d_backward_data_acc(
                                      _stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dst.data_ptr(), ws.data_ptr(),
                                      ws.numel(), _ptr(dyam), 1 if acc else 0), "cstp_conv3d_backward_data"))
@@ -895,7 +921,7 @@ class _BNReluConv3d(torch.autograd.Function):
 
         with _span("conv3d_forward", lambda: _desc_key(desc)):
             # ("fa": a forward that carries the in_affine may run another kernel variant -- another pack -- than the plain one)
-            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "fa", desc, x.device,
+            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "fa", x.shape, x.device,
                          lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)), run)
         ctx.save_for_backward(x, gamma, mean, invstd, ss, w)
         ctx.desc, ctx.groups, ctx.relu, ctx.z_absmax = desc, groups, relu, zam
@@ -949,7 +975,7 @@ class _BNReluConv3d(torch.autograd.Function):
             if AUTOTUNE and (lib.cstp_gemm_get_split_terms(), 1) + _desc_key(desc) not in _tuned:
                 _autotune(lib, desc, 1, dy, w, dz, ws)
             with _span("conv3d_backward_data", lambda: _desc_key(desc)):
-                _packed_call(pw if w.data_ptr() == pw.data_ptr() else None, "d", desc, x.device,
+                _packed_call(pw if w.data_ptr() == pw.data_ptr() else None, "d", x.shape, x.device,
                              lib.cstp_conv3d_workspace_bytes(ctypes.byref(desc)),
                              lambda wsd: check(lib.cstp_conv3d_backward_data_acc(
                                  _stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dz.data_ptr(), wsd.data_ptr(),

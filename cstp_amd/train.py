@@ -241,7 +241,16 @@ class PretrainStep:
             ops.pack_plan = plan
             plan.tick()
             plan.armed = True
-            plan.replay("online")          # every online / predictor / head weight pack of this step: one launch
+            plan.replay("online")          # every online / predictor / head FORWARD weight pack of this step: one launch
+            self._pack_side = None
+            if plan.state == "replay" and "online_d" in plan.tables and clip_1.is_cuda:
+                # ... and their data-gradient packs beside the forward pass, on the weight-gradient side stream
+                main = torch.cuda.current_stream(clip_1.device)
+                side = ops._side_stream(clip_1.device)
+                side.wait_stream(main)     # (the optimizer step that wrote the weights ran on the main stream)
+                with torch.cuda.stream(side):
+                    plan.replay("online_d")
+                self._pack_side = side
         try:
             with sync_ctx:
                 out = self._forward_backward(clip_1, clip_2, spa, tem, pb, rot_1, rot_2)
@@ -286,6 +295,9 @@ class PretrainStep:
             # every rank holds the same global loss; DDP will average the per-rank gradients
             objective = loss_total + (self.ntxent_weight * self.ntxent.ddp_scale) * nt
         self.optimizer.zero_grad()
+        if getattr(self, "_pack_side", None) is not None:      # the data-gradient weight packs (ops.PackPlan) must have landed
+            torch.cuda.current_stream(clip_1.device).wait_stream(self._pack_side)
+            self._pack_side = None
         objective.backward()
         return StepOutput(loss_total.detach(), loss_byol.detach(), [c.detach() for c in ce], None,
                           None if nt is None else nt.detach(), [l.detach() for l in logits])

@@ -173,6 +173,9 @@ typedef struct cstp_pack_rec {
 int cstp_pack_mode(int32_t mode);
 int32_t cstp_pack_recorded(cstp_pack_rec* out, int32_t cap);
 int cstp_pack_replay(void* stream, const cstp_pack_rec* recs_dev, const int32_t* first_block_dev, int32_t n, int32_t total_blocks);
+/* ... or, instead of mode 2 around every call: REGISTER the workspaces (the records' dst pointers) whose packs the caller replays --
+ * a call that receives a registered workspace skips its pack (on = 0: unregister; n = 0 with on = 0: forget all).  Process-wide. */
+int cstp_pack_register(const void* const* workspaces, int32_t n, int32_t on);
 
 /* Which kernel variant the next forward (mode 0) / backward_data (mode 1) / backward_weight (mode 2) call with this
  * descriptor will run: out[0] = rows per block tile, out[1] = positions (mode 2: (tap, channel) columns) per block tile,

@@ -13,9 +13,17 @@ python3 bench.py --depth 34 --no-cpu-baseline --no-extras > $O/bench_r34_t16.jso
 python3 bench.py --depth 34 --batch 8 --frames 32 --no-cpu-baseline --no-extras > $O/bench_r34_t32_cfg4.json.log 2>>$O/bench_tune_run.err
 cp cstp_amd/tuned/*.json $O/
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/trace_overlap.log 2>&1
-CSTP_OVERLAP_WGRAD=0 CSTP_OVERLAP_TARGET=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o run -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/trace_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o run -- python3 $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-extras > $O/trace_overlap.log 2>&1
+CSTP_OVERLAP_WGRAD=0 CSTP_OVERLAP_TARGET=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o run -- python3 $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-extras > $O/trace_serial.log 2>&1
 cd $R
+python3 - $O/trace_serial/run_kernel_trace.csv > $O/launches_per_step.txt <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+ends = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+last = rows[ends[-4] + 1:ends[-1] + 1]
+packs = sum(1 for r in last if "pack_" in r["Kernel_Name"])
+print("kernel launches per training step (last 3 steps of the serial trace): %.0f; of them weight packs / replays: %.1f" % (len(last) / 3.0, packs / 3.0))
+PY
 python3 profiles/summarize.py --trace $O/trace_overlap/run_kernel_trace.csv 3 > $O/bench_last3steps_overlap.txt
 python3 profiles/summarize.py --trace $O/trace_serial/run_kernel_trace.csv 3 > $O/bench_last3steps_serial.txt
 cp $O/trace_overlap/run_kernel_stats.csv $O/bench_overlap_kernel_stats.csv
@@ -30,6 +38,10 @@ bash tools/pmc_chain.sh > $O/pmc_chain_S1_T1.txt 2>&1
 # the stamped record bench.py reports roofline.traffic from (commit: CSTP_COMMIT, the box has no .git)
 python3 tools/write_pmc_record.py $O/pmc_fwd.txt $O/pmc_dominant_kernel.json
 mkdir -p profiles/r04 && cp $O/pmc_dominant_kernel.json profiles/r04/pmc_dominant_kernel.json
+python3 tools/cpu_enqueue_time.py 10 > $O/host_enqueue.log 2>/dev/null
+# BASELINE configs[4]'s share (3D-ResNet-50, bf16 storage): the line with its roofline block, PMC passes on three bf16 layers
+python3 tools/bench_r3d.py --depth 50 --batch 4 --size 224 --steps 10 --act_dtype bf16 > $O/bench_r3d50_bf16.json.log 2>/dev/null
+for l in L1_3x3x3 L1_pw_out L2_3x3x3; do bash tools/pmc_b16.sh $l > $O/pmc_b16_$l.txt 2>&1; done
 python3 bench.py > $O/bench_default_run.json.log 2>$O/bench_default_run.err
 tail -1 $O/bench_default_run.json.log | cut -c1-300
 head -14 $O/bench_last3steps_serial.txt
