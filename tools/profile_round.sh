@@ -21,7 +21,7 @@ import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
 last = rows[ends[-4] + 1:ends[-1] + 1]
-packs = sum(1 for r in last if "pack_" in r["Kernel_Name"])
+packs = sum(1 for r in last if "pack_" in r["Kernel_Name"] and "unpack_" not in r["Kernel_Name"])
 print("kernel launches per training step (last 3 steps of the serial trace): %.0f; of them weight packs / replays: %.1f" % (len(last) / 3.0, packs / 3.0))
 PY
 python3 profiles/summarize.py --trace $O/trace_overlap/run_kernel_trace.csv 3 > $O/bench_last3steps_overlap.txt
