@@ -11,6 +11,8 @@
 // as `groups` successive F.batch_norm calls would.  The model uses groups = 2 to push both views
 // of a clip pair through one launch sequence (same weights, per-view statistics -- identical maths
 // to the reference's two calls, r21d_byol.py:359-360, with half the launches and twice the grid).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cstp {
@@ -464,6 +466,160 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
   if (cell != nullptr) absmax_slot(mx, cell);
 }
 
+// ---- SMALL tensors (npg * s <= BN_SMALL_E values per channel and group: the 7 x 7 and 14 x 14 stages) -------------------------
+// The three-launch sequence above costs such a tensor 35 - 60 us of launch latencies and near-empty blocks (one block per 98-value
+// row).  Here ONE block owns a channel: group after group it holds the group's values in registers, sums them (fp64, fixed
+// order: thread t takes values t, t + 256, ...; wave shuffles, then the four wave sums in wave order), does the channel's
+// bookkeeping exactly as bn_finalize_*_kernel, applies and writes.  The absmax by-product leaves through the slots
+// (absmax_store_kernel: one block, a plain store -- nothing has zeroed the cell here).
+constexpr int BN_SMALL_PT = 16;                     // values per thread and group
+constexpr int BN_SMALL_E = BN_SMALL_PT * 256;
+
+__global__ void __launch_bounds__(256)
+bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+                    float* __restrict__ running_var, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                    float2* __restrict__ ss, int c, int s, int npg, int groups, float eps, float momentum, int relu,
+                    unsigned* __restrict__ slots) {
+  __shared__ double sm[16];
+  __shared__ float s_ss[2];
+  const int ch = blockIdx.x, E = npg * s;
+  const double count = (double)E;
+  const float ga = gamma[ch], be = beta[ch];
+  float rm = 0.f, rv = 0.f;
+  if (threadIdx.x == 0 && running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  unsigned mx = 0;
+  for (int g = 0; g < groups; ++g) {
+    float v[BN_SMALL_PT];
+    size_t off[BN_SMALL_PT];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      const int r = e / s, i = e - r * s;
+      off[u] = ((size_t)(g * npg + r) * c + ch) * s + i;
+      v[u] = e < E ? x[off[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) { a0 += (double)v[u]; a1 += (double)v[u] * v[u]; }
+    a0 = block_sum(a0, sm);
+    a1 = block_sum(a1, sm);
+    if (threadIdx.x == 0) {
+      const double mu = a0 / count;
+      double var = a1 / count - mu * mu;
+      if (var < 0.0) var = 0.0;
+      save_mean[g * c + ch] = (float)mu;
+      const float isf = (float)(1.0 / sqrt(var + (double)eps));
+      save_invstd[g * c + ch] = isf;
+      const float scl = isf * ga;
+      s_ss[0] = scl; s_ss[1] = be - (float)mu * scl;
+      if (ss != nullptr) ss[g * c + ch] = make_float2(scl, be - (float)mu * scl);
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
+      rv = (float)((1.0 - momentum) * rv + momentum * unb);
+    }
+    __syncthreads();
+    const float sc = s_ss[0], sh = s_ss[1];
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      if (e >= E) continue;
+      float o = v[u] * sc + sh;
+      if (res != nullptr) o += res[off[u]];
+      if (relu) o = fmaxf(o, 0.f);
+      y[off[u]] = o;
+      const unsigned a = abs_bits(o);
+      mx = mx > a ? mx : a;
+    }
+    __syncthreads();                                  // s_ss is rewritten by the next group
+  }
+  if (threadIdx.x == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+  if (slots != nullptr) absmax_slot(mx, slots);
+}
+
+__global__ void __launch_bounds__(256)
+bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                    const float2* __restrict__ ss, float* __restrict__ dx, float* __restrict__ dres,
+                    float* __restrict__ dgamma, float* __restrict__ dbeta, int c, int s, int npg, int groups, int relu,
+                    int accumulate, unsigned* __restrict__ slots) {
+  __shared__ double sm[16];
+  __shared__ float s_g[2];
+  const int ch = blockIdx.x, E = npg * s;
+  const float inv_count = (float)(1.0 / (double)E);
+  const bool remask = relu && (y == nullptr);
+  const float ga = gamma[ch];
+  double t0 = 0.0, t1 = 0.0;
+  unsigned mx = 0;
+  for (int g = 0; g < groups; ++g) {
+    const int gc = g * c + ch;
+    const float mu = mean[gc], is = invstd[gc];
+    float sc = 0.f, sh = 0.f;
+    if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
+    float v[BN_SMALL_PT], gr[BN_SMALL_PT];
+    size_t off[BN_SMALL_PT];
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      const int r = e / s, i = e - r * s;
+      off[u] = ((size_t)(g * npg + r) * c + ch) * s + i;
+      v[u] = 0.f; gr[u] = 0.f;
+      if (e < E) {
+        v[u] = x[off[u]];
+        float gg = dy[off[u]];
+        if (remask) { if (!((v[u] * sc + sh) > 0.f)) gg = 0.f; }
+        else if (relu && !(y[off[u]] > 0.f)) gg = 0.f;
+        gr[u] = gg;
+      }
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) { a0 += (double)gr[u]; a1 += (double)(gr[u] * ((v[u] - mu) * is)); }
+    a0 = block_sum(a0, sm);
+    a1 = block_sum(a1, sm);
+    if (threadIdx.x == 0) { s_g[0] = (float)a0; s_g[1] = (float)a1; t0 += a0; t1 += a1; }
+    __syncthreads();
+    const float mb = s_g[0] * inv_count, mg = s_g[1] * inv_count;
+    const float k = ga * is;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      if (e >= E) continue;
+      if (dres != nullptr) dres[off[u]] = gr[u];
+      const float o = k * (gr[u] - mb - (v[u] - mu) * is * mg);
+      dx[off[u]] = o;
+      const unsigned a = abs_bits(o);
+      mx = mx > a ? mx : a;
+    }
+    __syncthreads();                                  // s_g is rewritten by the next group
+  }
+  if (threadIdx.x == 0) {
+    dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+    dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
+  }
+  if (slots != nullptr) absmax_slot(mx, slots);
+}
+
+// one block: the maximum of n slots (a multiple of 4) STORED into the cell
+__global__ void __launch_bounds__(256) absmax_store_kernel(const unsigned* __restrict__ slots, int n, unsigned* __restrict__ cell) {
+  __shared__ unsigned red[4];
+  unsigned mx = 0;
+  const uint4* s4 = reinterpret_cast<const uint4*>(slots);
+  for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+    const uint4 v = s4[i];
+    unsigned a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    a = a > b ? a : b;
+    mx = mx > a ? mx : a;
+  }
+  mx = wave_umax(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    *cell = a > b ? a : b;
+  }
+}
+
 // ---- BatchNorm1d (s == 1): one thread per feature, lanes along the contiguous feature axis ------
 __global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -568,6 +724,12 @@ static unsigned* bn_slots(void* ws, int n, int c, int groups) {
                                      align_up((size_t)groups * c * 2 * sizeof(float), 256));
 }
 
+// CSTP_BN_SMALL=0: every BatchNorm3d through the three-launch sequence (A/B switch; read once)
+static bool bn_small_enabled() {
+  static const bool on = [] { const char* e = getenv("CSTP_BN_SMALL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups) {
   (void)s;
   if (n <= 0 || c <= 0 || groups <= 0 || (n % groups) != 0) return 0;
@@ -630,6 +792,17 @@ static int bn_forward_train_impl(void* stream, const float* x, const float* resi
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
+  if (pre_part == nullptr && (size_t)npg * s <= (size_t)BN_SMALL_E && bn_small_enabled()) {
+    unsigned* slots = y_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(c), dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
+                       save_mean, save_invstd, reinterpret_cast<float2*>(scale_shift), c, s, npg, groups, eps, momentum, relu, slots);
+    CSTP_LAUNCH_CHECK();
+    if (slots != nullptr) {
+      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 4, y_absmax);
+      CSTP_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   double* part = reinterpret_cast<double*>(ws);
   const int ns = bn_nsplit(npg, c);
   const bool v4 = (s % 4) == 0;
@@ -775,6 +948,17 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
+  if ((size_t)npg * s <= (size_t)BN_SMALL_E && bn_small_enabled()) {
+    unsigned* slots = dx_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
+                       dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
+    CSTP_LAUNCH_CHECK();
+    if (slots != nullptr) {
+      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 4, dx_absmax);
+      CSTP_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   double* part = reinterpret_cast<double*>(ws);
   const int ns = bn_nsplit(npg, c);
   float* gsum = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +

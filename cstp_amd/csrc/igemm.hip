@@ -736,6 +736,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #include "igemm_twres.h"
 #include "igemm_wpatch.h"
 #include "igemm_wtpatch.h"
+#include "linear.h"
 namespace cstp {
 
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
@@ -982,6 +983,35 @@ static bool native_only() {
   }();
   return env_f32 || g_split_terms.load(std::memory_order_relaxed) == 1;
 }
+// Fully connected layers on <= 32 rows (linear.h): exact fp32 FMAs on weight-streaming kernels instead of a one-tile GEMM.
+// CSTP_LINEAR=0 keeps them on the convolution kernels; so do the native-f32 mode (every GEMM on v_mfma_f32 there) and a pinned /
+// timed tile.
+static bool linear_shape(const cstp_conv_desc& d) {
+  static const bool on = [] { const char* e = getenv("CSTP_LINEAR"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || g_force_tile != nullptr || native_only()) return false;
+  return d.d == 1 && d.h == 1 && d.w == 1 && d.kt == 1 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 &&
+         d.pt == 0 && d.ph == 0 && d.pw == 0 && d.n <= LIN_NMAX;
+}
+// returns false when the call does not qualify (alignment, workspace): the caller falls through to the convolution kernels
+static bool run_linear(hipStream_t s, const cstp_conv_desc& d, bool dgrad, const float* a, const float* w, const float* bias, float* out,
+                       void* ws, size_t ws_bytes, bool accumulate) {
+  const int R = dgrad ? d.k : d.c, J = dgrad ? d.c : d.k;            // reduction length, output features
+  if ((R % LIN_SLICE) != 0 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(ws)) & 15) != 0) return false;
+  const int S = R / LIN_SLICE;
+  if ((size_t)S * d.n * J * sizeof(float) > ws_bytes) return false;
+  float* part = reinterpret_cast<float*>(ws);
+  const dim3 grid((unsigned)cdiv(J, 256), (unsigned)S);
+  if (dgrad) {
+    if (d.n <= 16) hipLaunchKernelGGL((linear_dgrad_part_kernel<16>), grid, dim3(256), 0, s, a, w, part, d.n, d.c, d.k);
+    else hipLaunchKernelGGL((linear_dgrad_part_kernel<32>), grid, dim3(256), 0, s, a, w, part, d.n, d.c, d.k);
+  } else {
+    if (d.n <= 16) hipLaunchKernelGGL((linear_fwd_part_kernel<16>), grid, dim3(256), 0, s, a, w, part, d.n, d.c, d.k);
+    else hipLaunchKernelGGL((linear_fwd_part_kernel<32>), grid, dim3(256), 0, s, a, w, part, d.n, d.c, d.k);
+  }
+  hipLaunchKernelGGL(linear_reduce_kernel, dim3((unsigned)cdiv(d.n * J, 256)), dim3(256), 0, s, part, bias, out, S, d.n, J, accumulate ? 1 : 0);
+  return true;
+}
+
 // deterministic mode (cstp_set_deterministic / CSTP_DETERMINISTIC=1): weight gradients through a two-stage split-K reduction
 // (every split writes its own slab, unpack sums them in order) instead of f32 atomics: bit-reproducible, for debugging
 constexpr int DET_MAX_SPLITS = 32;
@@ -1591,6 +1621,10 @@ extern "C" int cstp_conv3d_forward_am(void* stream, const cstp_conv_desc* desc, 
   float* wp = reinterpret_cast<float*>(ws);
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
+  if (ia.ss == nullptr && linear_shape(d) && run_linear(s, d, false, x, w, bias, y, ws, ws_bytes, false)) {
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   // the fused input transform on the f16-pair gather kernel (igemm_k1s<.., AFF>): see aff_split_ok
   const bool aff_split = ia.ss != nullptr && p.f_t.sp == 1 && !p.f_straddle &&
                          aff_split_ok(d, ia, x_absmax, (long)p.Do * p.Ho * p.Wo, tile_bn(p.f_t));
@@ -1665,6 +1699,10 @@ extern "C" int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc*
                "tensor too large for 32-bit byte offsets (>= 4 GiB)");
   hipStream_t s = as_stream(stream);
   float* wp = reinterpret_cast<float*>(ws);
+  if (linear_shape(d) && run_linear(s, d, true, dy, w, nullptr, dx, ws, ws_bytes, accumulate != 0)) {
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   if (p.d_t.sp == 2 && tpatch_geom_ok(d) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) != 0) {
     p.d_t = Tile{9, 1, 0, 1, 1};
     p.d_Mp = cdiv(d.c, tile_bm(p.d_t)) * tile_bm(p.d_t);
@@ -1688,6 +1726,12 @@ extern "C" int cstp_conv3d_backward_data_acc(void* stream, const cstp_conv_desc*
   const int d_bm = tile_bm(p.d_t), d_bn = tile_bn(p.d_t);
   const int ntx = cdiv(npos_max, d_bn), ntm = cdiv(d.c, d_bm);
   dim3 grid((unsigned)(align_up(ntx, 8) * ntm), (unsigned)nclass, 1);
+  if (p.ntaps == 1 && nclass > 1 && d.pt == 0 && d.ph == 0 && d.pw == 0) {
+    // a strided pointwise layer (the shortcut's spatial half, r21d_byol.py:122-125): only stride class 0 holds a tap, the other
+    // positions of dx are exact zeros -- one fill instead of three classes of strided zero stores (or nothing when accumulating)
+    if (!accumulate) CSTP_REQUIRE(hipMemsetAsync(dx, 0, (size_t)d.n * d.c * d.d * d.h * d.w * sizeof(float), s) == hipSuccess, "hipMemsetAsync");
+    grid.y = 1;
+  }
   if (d_split) run_k1s<true>(p.d_t, grid, s, g, d, p.ntaps, p.d_Kp, w, dy, (size_t)d.n * d.k * p.Do * p.Ho * p.Wo, nullptr, dx, ntx,
                              ntm, ws, plan_main_bytes(d, p), dy_absmax);
   else launch_k1<true, false, false>(p.d_t, grid, s, g, wp, dy, nullptr, dx, ntx, ntm, nullptr, 1, 0);

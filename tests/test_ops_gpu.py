@@ -56,7 +56,9 @@ def test_conv3d_fwd_bwd(cfg):
     assert rel_err(wg.grad, wt.grad) < TOL
 
 
-@pytest.mark.parametrize("b,fin,fout", [(16, 512, 4096), (16, 4096, 512), (4, 1024, 5), (2, 512, 512), (130, 70, 33)])
+# (<= 32 rows, reduction length a multiple of 4: the weight-streaming kernels of csrc/linear.h; else the 1x1x1 convolution)
+@pytest.mark.parametrize("b,fin,fout", [(16, 512, 4096), (16, 4096, 512), (4, 1024, 5), (2, 512, 512), (130, 70, 33), (32, 4096, 512),
+                                        (32, 512, 4096), (32, 1024, 1000), (17, 100, 36), (32, 70, 33), (33, 512, 64)])
 def test_linear_fwd_bwd(b, fin, fout):
     from cstp_amd import ops
     x = _rand((b, fin), 4).requires_grad_(True)
@@ -90,6 +92,11 @@ BNS = [
     # statistics folded inside the apply passes (BnFin) on the scalar path (round-3 ADVICE)
     ((80, 8, 5, 3, 3), False, True),
     ((72, 6, 3, 5, 5), True, True),
+    # the single-launch kernels for small tensors (bn_small_*_kernel: <= 4096 values per channel and group): the 7 x 7 stage's
+    # shape class, the boundary (8 * 512 = 4096 values) and the first size past it (three-launch sequence)
+    ((16, 40, 2, 7, 7), True, True),
+    ((8, 5, 8, 8, 8), False, True),
+    ((8, 5, 8, 8, 9), True, True),
 ]
 
 
@@ -127,7 +134,8 @@ def test_bn_act_fwd_bwd(shape, use_res, relu):
         assert rel_err(rg.grad, res.grad) < TOL
 
 
-@pytest.mark.parametrize("shape,relu", [((6, 24, 2, 6, 6), True), ((8, 40), True), ((4, 9, 1, 7, 7), False)])
+@pytest.mark.parametrize("shape,relu", [((6, 24, 2, 6, 6), True), ((8, 40), True), ((4, 9, 1, 7, 7), False), ((32, 20, 2, 7, 7), True),
+                                        ((16, 6, 8, 8, 8), True)])
 def test_bn_groups_equal_successive_calls(shape, relu):
     """groups=2 over a 2B batch == two successive F.batch_norm calls (per-view stats, sequential running stats)."""
     from cstp_amd import ops
@@ -281,3 +289,28 @@ def test_flat_utils():
         ops.sgd_step_(pg, g2, buf, lr, 0.9, 5e-4, coef, step == 0, True)
         assert rel_err(g2, g * ref_coef) < 1e-6
     assert rel_err(pg, p.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("shape,groups,use_res", [((32, 24, 2, 7, 7), 2, True), ((16, 10, 8, 8, 8), 2, False), ((6, 7, 1, 5, 5), 1, False)])
+def test_bn_small_tensor_kernels_leave_the_absmax_cells(shape, groups, use_res):
+    """bn_small_fwd / bwd_kernel (one launch per pass + a one-block fold that STORES the cell): max |y| and max |dx| as bits."""
+    from cstp_amd import ops
+    ops.set_split_terms(2)
+    try:
+        c = shape[1]
+        x = (_rand(shape, 51) * 3).float().cuda().requires_grad_(True)
+        res = _rand(shape, 52).float().cuda().requires_grad_(True) if use_res else None
+        g = (_rand((c,), 53).abs() + 0.5).float().cuda().requires_grad_(True)
+        b = _rand((c,), 54).float().cuda().requires_grad_(True)
+        for _ in range(2):                                # the second call finds the cell of the first one used, not zeroed
+            y = ops.batch_norm_act(x, g, b, None, None, res, True, groups=groups)
+            cell, ver = y._cstp_absmax
+            assert ver == y._version
+            assert int(cell.item()) == int(y.detach().abs().max().view(torch.int32).item())
+        dy = _rand(shape, 55).float().cuda()
+        y.backward(dy)
+        dcell = ops._absmax_of(x.grad)
+        if dcell is not None:
+            assert int(dcell.item()) == int(x.grad.abs().max().view(torch.int32).item())
+    finally:
+        ops.set_split_terms(0)

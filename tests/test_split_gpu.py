@@ -22,6 +22,7 @@ GEOMS = {
     "S7": ((1, 512, 2, 7, 7), 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),           # long reduction, few positions
     "odd": ((3, 40, 3, 9, 11), 136, (3, 3, 3), (1, 2, 1), (1, 1, 1)),           # ragged everything, 27 taps, channel padding
     "lin": ((6, 96, 1, 1, 1), 40, (1, 1, 1), (1, 1, 1), (0, 0, 0)),             # nn.Linear as a 1x1x1 convolution
+    "short": ((2, 64, 4, 14, 14), 42, (1, 1, 1), (1, 2, 2), (0, 0, 0)),         # shortcut's spatial half: strided pointwise
 }
 
 
@@ -592,9 +593,10 @@ def test_stem_weight_gradient_on_the_split_kernel(name, mt, blocks):
 
 
 @pytest.mark.parametrize("name,tile", [("S1", (2, 4, 0, 0)), ("S1", (1, 4, 0, 0)), ("S1", (0, 2, 1, 1)), ("S2s", (1, 9, 0, 0)),
-                                       ("S2s", (0, 2, 2, 1)), ("T2s", (1, 4, 0, 0)), ("odd", (1, 3, 0, 0)), ("lin", (1, 2, 0, 0))],
+                                       ("S2s", (0, 2, 2, 1)), ("T2s", (1, 4, 0, 0)), ("odd", (1, 3, 0, 0)), ("lin", (1, 2, 0, 0)),
+                                       ("short", (1, 4, 0, 0)), ("short", (0, 2, 2, 1))],
                          ids=["patch", "split", "native", "split strided", "native strided", "split temporal strided", "split odd",
-                              "split linear"])
+                              "split linear", "split strided pointwise", "native strided pointwise"])
 def test_data_gradient_accumulate_flag(name, tile):
     """cstp_conv3d_backward_data_acc: dx += the data gradient (the sum of a residual connection's two gradients formed in the
     convolution's epilogue, ops.GradJoin) on every kernel family, incl. the stride-parity classes of a strided layer."""
