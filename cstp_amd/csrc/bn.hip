@@ -466,16 +466,22 @@ bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
   if (cell != nullptr) absmax_slot(mx, cell);
 }
 
-// ---- SMALL tensors (npg * s <= BN_SMALL_E values per channel and group: the 7 x 7 and 14 x 14 stages) -------------------------
+// ---- SMALL tensors (npg * s <= BN_SMALL_E = 16 384 values per channel and group: the 7 x 7 and 14 x 14 stages) ----------------
 // The three-launch sequence above costs such a tensor 35 - 60 us of launch latencies and near-empty blocks (one block per 98-value
 // row).  Here ONE block owns a channel: group after group it holds the group's values in registers, sums them (fp64, fixed
 // order: thread t takes values t, t + 256, ...; wave shuffles, then the four wave sums in wave order), does the channel's
 // bookkeeping exactly as bn_finalize_*_kernel, applies and writes.  The absmax by-product leaves through the slots
 // (absmax_store_kernel: one block, a plain store -- nothing has zeroed the cell here).
 constexpr int BN_SMALL_PT = 16;                     // values per thread and group
-constexpr int BN_SMALL_E = BN_SMALL_PT * 256;
+constexpr int BN_SMALL_E = BN_SMALL_PT * 1024;      // ... with blocks of 256 (<= 4096 values) or 1024 threads
 
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ unsigned bn_small_off(int e, int s, int g, int npg, int c, int ch) {
+  const int r = e / s, i = e - r * s;
+  return ((unsigned)(g * npg + r) * c + ch) * s + i;       // (host: the tensor has < 2^31 elements)
+}
+
+template <int TPB>
+__global__ void __launch_bounds__(TPB)
 bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
                     float* __restrict__ running_var, float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -491,14 +497,11 @@ bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
   unsigned mx = 0;
   for (int g = 0; g < groups; ++g) {
     float v[BN_SMALL_PT];
-    size_t off[BN_SMALL_PT];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int u = 0; u < BN_SMALL_PT; ++u) {
-      const int e = u * 256 + threadIdx.x;
-      const int r = e / s, i = e - r * s;
-      off[u] = ((size_t)(g * npg + r) * c + ch) * s + i;
-      v[u] = e < E ? x[off[u]] : 0.f;
+      const int e = u * TPB + threadIdx.x;
+      v[u] = e < E ? x[bn_small_off(e, s, g, npg, c, ch)] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < BN_SMALL_PT; ++u) { a0 += (double)v[u]; a1 += (double)v[u] * v[u]; }
@@ -522,22 +525,28 @@ bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, 
     const float sc = s_ss[0], sh = s_ss[1];
 #pragma unroll
     for (int u = 0; u < BN_SMALL_PT; ++u) {
-      const int e = u * 256 + threadIdx.x;
+      const int e = u * TPB + threadIdx.x;
       if (e >= E) continue;
+      const unsigned off = bn_small_off(e, s, g, npg, c, ch);
       float o = v[u] * sc + sh;
-      if (res != nullptr) o += res[off[u]];
+      if (res != nullptr) o += res[off];
       if (relu) o = fmaxf(o, 0.f);
-      y[off[u]] = o;
+      y[off] = o;
       const unsigned a = abs_bits(o);
       mx = mx > a ? mx : a;
     }
     __syncthreads();                                  // s_ss is rewritten by the next group
   }
   if (threadIdx.x == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
-  if (slots != nullptr) absmax_slot(mx, slots);
+  if (slots != nullptr) {                             // 16 slots per block (the fold takes the maximum; unused ones hold 0)
+    mx = wave_umax(mx);
+    if ((threadIdx.x & 63) == 0) slots[blockIdx.x * 16 + (threadIdx.x >> 6)] = mx;
+    else if (threadIdx.x < 16 && threadIdx.x >= TPB / 64) slots[blockIdx.x * 16 + threadIdx.x] = 0;
+  }
 }
 
-__global__ void __launch_bounds__(256)
+template <int TPB>
+__global__ void __launch_bounds__(TPB)
 bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                     const float2* __restrict__ ss, float* __restrict__ dx, float* __restrict__ dres,
@@ -557,18 +566,16 @@ bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
     float sc = 0.f, sh = 0.f;
     if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
     float v[BN_SMALL_PT], gr[BN_SMALL_PT];
-    size_t off[BN_SMALL_PT];
 #pragma unroll
     for (int u = 0; u < BN_SMALL_PT; ++u) {
-      const int e = u * 256 + threadIdx.x;
-      const int r = e / s, i = e - r * s;
-      off[u] = ((size_t)(g * npg + r) * c + ch) * s + i;
+      const int e = u * TPB + threadIdx.x;
       v[u] = 0.f; gr[u] = 0.f;
       if (e < E) {
-        v[u] = x[off[u]];
-        float gg = dy[off[u]];
+        const unsigned off = bn_small_off(e, s, g, npg, c, ch);
+        v[u] = x[off];
+        float gg = dy[off];
         if (remask) { if (!((v[u] * sc + sh) > 0.f)) gg = 0.f; }
-        else if (relu && !(y[off[u]] > 0.f)) gg = 0.f;
+        else if (relu && !(y[off] > 0.f)) gg = 0.f;
         gr[u] = gg;
       }
     }
@@ -583,11 +590,12 @@ bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
     const float k = ga * is;
 #pragma unroll
     for (int u = 0; u < BN_SMALL_PT; ++u) {
-      const int e = u * 256 + threadIdx.x;
+      const int e = u * TPB + threadIdx.x;
       if (e >= E) continue;
-      if (dres != nullptr) dres[off[u]] = gr[u];
+      const unsigned off = bn_small_off(e, s, g, npg, c, ch);
+      if (dres != nullptr) dres[off] = gr[u];
       const float o = k * (gr[u] - mb - (v[u] - mu) * is * mg);
-      dx[off[u]] = o;
+      dx[off] = o;
       const unsigned a = abs_bits(o);
       mx = mx > a ? mx : a;
     }
@@ -597,7 +605,11 @@ bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, co
     dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
     dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
   }
-  if (slots != nullptr) absmax_slot(mx, slots);
+  if (slots != nullptr) {
+    mx = wave_umax(mx);
+    if ((threadIdx.x & 63) == 0) slots[blockIdx.x * 16 + (threadIdx.x >> 6)] = mx;
+    else if (threadIdx.x < 16 && threadIdx.x >= TPB / 64) slots[blockIdx.x * 16 + threadIdx.x] = 0;
+  }
 }
 
 // one block: the maximum of n slots (a multiple of 4) STORED into the cell
@@ -717,7 +729,11 @@ __global__ void bn1d_eval_kernel(const float* __restrict__ x, const float* __res
 
 using namespace cstp;
 
-static size_t bn_slot_bytes(int n, int c, int s) { return align_up((size_t)n * c * cdiv(s, 1024) * 4 * sizeof(unsigned), 256); }
+static size_t bn_slot_bytes(int n, int c, int s) {      // 4 per block of an apply pass; 16 per channel for the small-tensor kernels
+  size_t slots = (size_t)n * c * cdiv(s, 1024) * 4;
+  if (slots < (size_t)c * 16) slots = (size_t)c * 16;
+  return align_up(slots * sizeof(unsigned), 256);
+}
 static unsigned* bn_slots(void* ws, int n, int c, int groups) {
   const int npg = n / groups;
   return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + align_up((size_t)c * groups * bn_nsplit(npg, c) * 2 * sizeof(double), 256) +
@@ -728,6 +744,11 @@ static unsigned* bn_slots(void* ws, int n, int c, int groups) {
 static bool bn_small_enabled() {
   static const bool on = [] { const char* e = getenv("CSTP_BN_SMALL"); return !(e && e[0] == '0'); }();
   return on;
+}
+// the single-launch kernels: <= 16 384 values per (channel, group), 32-bit element offsets, 16 slots per channel in the workspace
+static bool bn_small_ok(int n, int c, int s, int groups) {
+  const size_t e = (size_t)(n / groups) * s;
+  return bn_small_enabled() && e <= (size_t)BN_SMALL_E && (size_t)n * c * s < (1ull << 31);
 }
 
 extern "C" size_t cstp_bn_workspace_bytes(int32_t n, int32_t c, int32_t s, int32_t groups) {
@@ -792,13 +813,17 @@ static int bn_forward_train_impl(void* stream, const float* x, const float* resi
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
-  if (pre_part == nullptr && (size_t)npg * s <= (size_t)BN_SMALL_E && bn_small_enabled()) {
+  if (pre_part == nullptr && bn_small_ok(n, c, s, groups)) {
     unsigned* slots = y_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
-    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(c), dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
-                       save_mean, save_invstd, reinterpret_cast<float2*>(scale_shift), c, s, npg, groups, eps, momentum, relu, slots);
+    if ((size_t)npg * s <= (size_t)BN_SMALL_PT * 256)
+      hipLaunchKernelGGL(bn_small_fwd_kernel<256>, dim3(c), dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
+                         save_mean, save_invstd, reinterpret_cast<float2*>(scale_shift), c, s, npg, groups, eps, momentum, relu, slots);
+    else
+      hipLaunchKernelGGL(bn_small_fwd_kernel<1024>, dim3(c), dim3(1024), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
+                         save_mean, save_invstd, reinterpret_cast<float2*>(scale_shift), c, s, npg, groups, eps, momentum, relu, slots);
     CSTP_LAUNCH_CHECK();
     if (slots != nullptr) {
-      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 4, y_absmax);
+      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 16, y_absmax);
       CSTP_LAUNCH_CHECK();
     }
     return 0;
@@ -948,13 +973,17 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
-  if ((size_t)npg * s <= (size_t)BN_SMALL_E && bn_small_enabled()) {
+  if (bn_small_ok(n, c, s, groups)) {
     unsigned* slots = dx_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
-    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
-                       dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
+    if ((size_t)npg * s <= (size_t)BN_SMALL_PT * 256)
+      hipLaunchKernelGGL(bn_small_bwd_kernel<256>, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
+                         dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
+    else
+      hipLaunchKernelGGL(bn_small_bwd_kernel<1024>, dim3(c), dim3(1024), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
+                         dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
     CSTP_LAUNCH_CHECK();
     if (slots != nullptr) {
-      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 4, dx_absmax);
+      hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 16, dx_absmax);
       CSTP_LAUNCH_CHECK();
     }
     return 0;

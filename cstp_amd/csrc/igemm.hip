@@ -1816,6 +1816,13 @@ extern "C" int cstp_conv3d_backward_weight_acc(void* stream, const cstp_conv_des
   g.Cp = p.w_Cp; g.M = d.k; g.Mp = 0; g.Ktot = p.w_Jtot;
   InAffine ia;
   if (parse_in_affine(in_affine, d, ia)) return 1;
+  if (ia.ss == nullptr && linear_shape(d)) {
+    const dim3 lgrid((unsigned)cdiv(d.c, 256), (unsigned)cdiv(d.k, 16));
+    if (d.n <= 16) hipLaunchKernelGGL((linear_wgrad_kernel<16>), lgrid, dim3(256), 0, s, dy, x, dw, d.n, d.c, d.k, accumulate ? 1 : 0);
+    else hipLaunchKernelGGL((linear_wgrad_kernel<32>), lgrid, dim3(256), 0, s, dy, x, dw, d.n, d.c, d.k, accumulate ? 1 : 0);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   if (p.w_patch && ia.ss == nullptr) {
     // igemm_k2p.  Slab(s) + absmax cells zeroed together; in deterministic mode one slab per frame-range split.
     const size_t det_stride_p = det ? slab_al / sizeof(float) : 0;

@@ -89,6 +89,45 @@ linear_dgrad_part_kernel(const float* __restrict__ dy, const float* __restrict__
   }
 }
 
+// dw[k][c] = (accumulate ? dw[k][c] : 0) + sum_n dy[n][k] * x[n][c], rows in order.     grid (ceil(C / 256), ceil(K / 16))
+// lane = input feature c holding x[0 .. N)[c]; the 16 rows k of the block take dy through scalar loads.  8 MB of dw written once.
+template <int NB>
+__global__ void __launch_bounds__(256)
+linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int N, int C, int K, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 16;
+  const int cc = c < C ? c : C - 1;
+  float xv[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n) xv[n] = n < N ? x[(size_t)n * C + cc] : 0.f;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  if (k0 + 16 <= K) {                                // (block-uniform) sixteen consecutive dy values per row: one scalar load
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const float* __restrict__ row = dy + (size_t)(n < N ? n : N - 1) * K + k0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(row[j], xv[n], acc[j]);
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const float* __restrict__ row = dy + (size_t)(n < N ? n : N - 1) * K;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = __builtin_fmaf(row[k0 + j < K ? k0 + j : K - 1], xv[n], acc[j]);
+    }
+  }
+  if (c < C) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (k0 + j < K) {
+        float* o = dw + (size_t)(k0 + j) * C + c;
+        *o = accumulate ? *o + acc[j] : acc[j];
+      }
+    }
+  }
+}
+
 // out[n][j] = (accumulate ? out[n][j] : 0) + bias[j] + sum_s part[s][n][j], slices in order
 __global__ void __launch_bounds__(256)
 linear_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out, int S, int N, int J,

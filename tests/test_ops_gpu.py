@@ -97,6 +97,10 @@ BNS = [
     ((16, 40, 2, 7, 7), True, True),
     ((8, 5, 8, 8, 8), False, True),
     ((8, 5, 8, 8, 9), True, True),
+    # ... on blocks of 1024 threads (4096 < values <= 16 384: the 14 x 14 stage), its boundary, and the first size past it
+    ((16, 12, 4, 14, 14), True, True),
+    ((16, 4, 4, 16, 16), False, True),
+    ((17, 4, 4, 16, 16), True, False),
 ]
 
 
@@ -135,7 +139,7 @@ def test_bn_act_fwd_bwd(shape, use_res, relu):
 
 
 @pytest.mark.parametrize("shape,relu", [((6, 24, 2, 6, 6), True), ((8, 40), True), ((4, 9, 1, 7, 7), False), ((32, 20, 2, 7, 7), True),
-                                        ((16, 6, 8, 8, 8), True)])
+                                        ((16, 6, 8, 8, 8), True), ((32, 6, 4, 14, 14), True)])
 def test_bn_groups_equal_successive_calls(shape, relu):
     """groups=2 over a 2B batch == two successive F.batch_norm calls (per-view stats, sequential running stats)."""
     from cstp_amd import ops
@@ -291,7 +295,8 @@ def test_flat_utils():
     assert rel_err(pg, p.detach()) < 1e-6
 
 
-@pytest.mark.parametrize("shape,groups,use_res", [((32, 24, 2, 7, 7), 2, True), ((16, 10, 8, 8, 8), 2, False), ((6, 7, 1, 5, 5), 1, False)])
+@pytest.mark.parametrize("shape,groups,use_res", [((32, 24, 2, 7, 7), 2, True), ((16, 10, 8, 8, 8), 2, False), ((6, 7, 1, 5, 5), 1, False),
+                                                  ((32, 9, 4, 14, 14), 2, True), ((2, 3, 1, 3, 3), 1, False)])
 def test_bn_small_tensor_kernels_leave_the_absmax_cells(shape, groups, use_res):
     """bn_small_fwd / bwd_kernel (one launch per pass + a one-block fold that STORES the cell): max |y| and max |dx| as bits."""
     from cstp_amd import ops
