@@ -51,7 +51,10 @@ template <int MODE, bool VEC4>
 __global__ void __launch_bounds__(256)
 bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                  const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part, int npg,
-                 int c, int s, int nsplit, int relu, const float2* __restrict__ ss, unsigned* __restrict__ cell = nullptr) {
+                 int c, int s, int nsplit, int relu, const float2* __restrict__ ss, unsigned* __restrict__ cell = nullptr,
+                 float* __restrict__ gout = nullptr) {
+  // gout (MODE 1): the masked gradient g is also WRITTEN there -- it is the residual branch's gradient, and the apply pass then
+  // reads (x, g) instead of (x, y, dy): seven passes over the tensor instead of eight
   __shared__ double sm[16];
   // (the absmax cell of the apply pass two launches on: absmax_fold_kernel takes the maximum into it)
   if (cell != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *cell = 0;
@@ -87,6 +90,7 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
           }
+          if (gout != nullptr) reinterpret_cast<float4*>(gout + base)[i] = g;
           a0 += (double)g.x + (double)g.y + (double)g.z + (double)g.w;
           a1 += (double)(g.x * ((v.x - mu) * is)) + (double)(g.y * ((v.y - mu) * is)) +
                 (double)(g.z * ((v.z - mu) * is)) + (double)(g.w * ((v.w - mu) * is));
@@ -101,6 +105,7 @@ bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const
           float g = dy[base + i];
           if (remask) { if (!((v * sc + sh) > 0.f)) g = 0.f; }
           else if (relu && !(y[base + i] > 0.f)) g = 0.f;
+          if (gout != nullptr) gout[base + i] = g;
           a0 += (double)g; a1 += (double)(g * ((v - mu) * is));
         }
       }
@@ -973,14 +978,12 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
     return 0;
   }
   CSTP_REQUIRE(ws && ws_bytes >= cstp_bn_workspace_bytes(n, c, s, groups), "workspace too small");
-  if (bn_small_ok(n, c, s, groups)) {
+  // (the backward pass on 1024-thread blocks measured SLOWER than the three-launch sequence on the 14 x 14 stage -- 77 vs 56 us at
+  //  576 channels: two tensors in registers per thread -- so only the 256-thread form is used here)
+  if (bn_small_ok(n, c, s, groups) && (size_t)npg * s <= (size_t)BN_SMALL_PT * 256) {
     unsigned* slots = dx_absmax != nullptr ? bn_slots(ws, n, c, groups) : nullptr;
-    if ((size_t)npg * s <= (size_t)BN_SMALL_PT * 256)
-      hipLaunchKernelGGL(bn_small_bwd_kernel<256>, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
-                         dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
-    else
-      hipLaunchKernelGGL(bn_small_bwd_kernel<1024>, dim3(c), dim3(1024), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
-                         dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
+    hipLaunchKernelGGL(bn_small_bwd_kernel<256>, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd, ss2, dx, dresidual,
+                       dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0, slots);
     CSTP_LAUNCH_CHECK();
     if (slots != nullptr) {
       hipLaunchKernelGGL(absmax_store_kernel, dim3(1), dim3(256), 0, st, slots, c * 16, dx_absmax);
@@ -994,9 +997,13 @@ extern "C" int cstp_bn_backward_am(void* stream, const float* x, const float* y,
                                          align_up((size_t)c * groups * ns * 2 * sizeof(double), 256));
   const bool v4 = (s % 4) == 0;
   const dim3 rgrid(c, groups * ns);
-  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax);
-  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax);
+  // residual + ReLU (a block's last BatchNorm): the reduction pass leaves the masked gradient in dresidual, the apply pass reads it
+  const bool g_first = relu && y != nullptr && dresidual != nullptr && dresidual != dy;
+  float* gout = g_first ? dresidual : nullptr;
+  if (v4) hipLaunchKernelGGL((bn_reduce_kernel<1, true>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax, gout);
+  else hipLaunchKernelGGL((bn_reduce_kernel<1, false>), rgrid, dim3(256), 0, st, x, y, dy, save_mean, save_invstd, part, npg, c, s, ns, relu, ss2, dx_absmax, gout);
   CSTP_LAUNCH_CHECK();
+  if (g_first) { y = nullptr; dy = dresidual; dresidual = nullptr; relu = 0; }
   // (the finalize -- per-group sums for the dx pass, dgamma / dbeta -- is folded into the apply pass: BnFin)
   BnFin fin;
   memset(&fin, 0, sizeof(fin));
