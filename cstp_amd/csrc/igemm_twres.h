@@ -9,9 +9,9 @@
 //    traffic, no DMA wave and no weight wait in the steady state;
 //  * the patch (8 + 2 frames x 28 columns x 32 channels, split f16 pairs: 35 KB) has ONE buffer: the consumers multiply the
 //    three K-tiles of a channel block without any barrier, then barrier A ("patch read"), the staging waves store the next
-//    channel block from the registers it has been waiting in (its loads were issued two channel blocks earlier), barrier B
-//    ("patch written").  The consumers idle between A and B (~25 % of a channel block's matrix work) -- irrelevant for a kernel
-//    that waits for memory -- except at the end of an item, where they run the EPILOGUE there;
+//    channel block -- transformed and split in registers BEFORE the barrier, beside the consumers' products (its loads were issued
+//    two channel blocks earlier) -- barrier B ("patch written").  The consumers idle between A and B for eight LDS stores per
+//    staging lane; at the end of an item they run the EPILOGUE there;
 //  * 16-byte staging loads, BatchNorm + ReLU of the input once per staged element (AFF), BatchNorm sums / range of the output
 //    from the epilogue (STATS), persistent XCD-ordered grid, transposed accumulator tile: igemm_k1t's.
 #pragma once
@@ -164,7 +164,13 @@ igemm_k1w(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     auto advance = [&]() __attribute__((always_inline)) {
       if (++l_cb == g.ncb) { l_cb = 0; ++l_it; set_item(l_it); }
     };
-    auto store_round = [&](const Task& k, Round& rd) __attribute__((always_inline)) {
+    // a round on its way into the patch, in two steps: prep_round turns the raw values into the packed (hi, lo) f16 pieces of
+    // its four LDS rows IN REGISTERS -- all of the staging arithmetic (BatchNorm + ReLU, split) -- and runs while the consumers
+    // still multiply the previous channel block; write_round is the eight 16-byte LDS stores, the only work left between the
+    // barriers A and B (the consumers wait there).  (First version: everything between A and B, ~1 600 cycles per channel block
+    // against ~2 000 of matrix work.)
+    struct Packed { uint4 ph[4], pl[4]; };
+    auto prep_round = [&](const Task& k, const Round& rd, Packed& pk) __attribute__((always_inline)) {
       float a[8], b[8];
       if constexpr (AFF) {
         int c0 = rd.cb * 32 + k.c8 * 8;
@@ -194,12 +200,18 @@ igemm_k1w(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
         split2h(z[2], z[3], sb, hh, ll); ph.y = hh; pl.y = ll;
         split2h(z[4], z[5], sb, hh, ll); ph.z = hh; pl.z = ll;
         split2h(z[6], z[7], sb, hh, ll); ph.w = hh; pl.w = ll;
-        if (k.ok) {
+        pk.ph[i] = ph; pk.pl[i] = pl;
+      }
+    };
+    auto write_round = [&](const Task& k, const Packed& pk) __attribute__((always_inline)) {
+      if (k.ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
           const int row = k.row + i;
           uint4* prow = patch + row * 8;
           const int x7 = row & 7;
-          prow[k.c8 ^ x7] = ph;
-          prow[(4 + k.c8) ^ x7] = pl;
+          prow[k.c8 ^ x7] = pk.ph[i];
+          prow[(4 + k.c8) ^ x7] = pk.pl[i];
         }
       }
     };
@@ -207,10 +219,13 @@ igemm_k1w(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     Round rm[2], rt[2];                                // by parity of the channel block they carry
     set_item(0);
     // ---- prologue: channel block 0 of the first item into the patch; blocks 1 and 2 requested
+    Packed pm, pt;
     load_round(tm, l_vm, rm[0]);
     load_round(tt, l_vt, rt[0]);
-    store_round(tm, rm[0]);
-    store_round(tt, rt[0]);
+    prep_round(tm, rm[0], pm);
+    prep_round(tt, rt[0], pt);
+    write_round(tm, pm);
+    write_round(tt, pt);
     advance();
     load_round(tm, l_vm, rm[1]);
     load_round(tt, l_vt, rt[1]);
@@ -226,10 +241,12 @@ igemm_k1w(const TGeom g, const uint4* __restrict__ wpk, const float* __restrict_
     const int total = nitems * g.ncb;
     auto boundary = [&](auto par_tag) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_tag)::value;    // parity of block X + 1
+      prep_round(tm, rm[PAR], pm);                      // (beside the consumers' products of block X)
+      prep_round(tt, rt[PAR], pt);
       __builtin_amdgcn_s_barrier();                     // A
-      store_round(tm, rm[PAR]);
+      write_round(tm, pm);
+      write_round(tt, pt);
       load_round(tm, l_vm, rm[PAR]);
-      store_round(tt, rt[PAR]);
       load_round(tt, l_vt, rt[PAR]);
       advance();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
