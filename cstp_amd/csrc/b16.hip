@@ -23,6 +23,7 @@
 //                              into fp32 slabs summed by b16_sum_slabs_kernel: 16 blocks x 432 K-tiles become 512 x 14.
 //   BatchNorm / pooling / cast: HBM-streaming, 16-byte (8 x bf16) accesses where rows allow.
 #include "common.h"
+#include "pack_b16.h"
 
 namespace cstp {
 
@@ -91,15 +92,7 @@ pad_b16_kernel(const u16* __restrict__ x, u16* __restrict__ xp, int planes, int 
 // data gradient:  wp[m = cin  (Mp rows)][k = tap * kout + ko]
 __global__ void __launch_bounds__(256)
 pack_w_b16_kernel(const float* __restrict__ w, u16* __restrict__ wp, int kout, int cin, int ntaps, int Mp, int Kw, int dgrad) {
-  const size_t total = (size_t)Mp * Kw;
-  const int inner = dgrad ? kout : cin, mreal = dgrad ? cin : kout;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int k = (int)(i % Kw), m = (int)(i / Kw);
-    const int tap = k / inner, c = k - tap * inner;
-    float v = 0.f;
-    if (m < mreal && tap < ntaps) v = dgrad ? w[((size_t)c * cin + m) * ntaps + tap] : w[((size_t)m * cin + c) * ntaps + tap];
-    wp[i] = f2bf(v);
-  }
+  pack_w_b16_body(w, wp, kout, cin, ntaps, Mp, Kw, dgrad, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- implicit-GEMM convolution, forward and data gradient ---------------------------------------------------------------------
@@ -1200,8 +1193,10 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
   const int Mp = (int)align_up((size_t)d->k, BM);
   u16* wp = reinterpret_cast<u16*>(ws);
   const bool pw = !q.tab && b16_pointwise(d, x) && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
-  if (!pw) {      // (pointwise forward: the kernel rounds the fp32 rows itself)
-    hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * q.Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
+  if (!pw && !pack_skip(wp)) {      // (pointwise forward: the kernel rounds the fp32 rows itself; pack plan: replayed by the caller)
+    const unsigned nb = b16_grid((size_t)Mp * q.Kw, 256);
+    pack_record_b16(w, wp, (int)nb, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
+    hipLaunchKernelGGL(pack_w_b16_kernel, dim3(nb), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, q.Kw, 0);
     CSTP_LAUNCH_CHECK();
   }
   B16Conv g;
@@ -1260,8 +1255,12 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
   const int Mp = (int)align_up((size_t)d->c, BM);
   const int Kw = q.ntaps * d->k;
   u16* wp = reinterpret_cast<u16*>(ws);
-  hipLaunchKernelGGL(pack_w_b16_kernel, dim3(b16_grid((size_t)Mp * Kw, 256)), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, Kw, 1);
-  CSTP_LAUNCH_CHECK();
+  if (!pack_skip(wp)) {
+    const unsigned nb = b16_grid((size_t)Mp * Kw, 256);
+    pack_record_b16(w, wp, (int)nb, d->k, d->c, q.ntaps, Mp, Kw, 1);
+    hipLaunchKernelGGL(pack_w_b16_kernel, dim3(nb), dim3(256), 0, st, w, wp, d->k, d->c, q.ntaps, Mp, Kw, 1);
+    CSTP_LAUNCH_CHECK();
+  }
   const int ksplit = b16_dgrad_split(d, q);
   float* slab = b16_slabs(ws, d, q);
   const size_t out_elems = (size_t)d->n * d->c * d->d * d->h * d->w;

@@ -737,6 +737,7 @@ igemm_k2(const Geom g, const float* __restrict__ dy, const float* __restrict__ x
 #include "igemm_wpatch.h"
 #include "igemm_wtpatch.h"
 #include "linear.h"
+#include "pack_b16.h"
 namespace cstp {
 
 static int pick_mt(int M) {   // K2 (weight gradient): rows per block = 32*mt, minimise padded rows
@@ -1129,11 +1130,20 @@ static thread_local std::vector<cstp_pack_rec> tl_pack_recs;
 static std::mutex g_prepacked_mu;
 static std::unordered_set<const void*> g_prepacked;
 static std::atomic<int> g_prepacked_n{0};
-static bool pack_skip(const void* dst) {
+bool pack_skip(const void* dst) {
   if (tl_pack_mode == 2) return true;
   if (tl_pack_mode == 1 || g_prepacked_n.load(std::memory_order_relaxed) == 0) return false;
   std::lock_guard<std::mutex> lk(g_prepacked_mu);
   return g_prepacked.count(dst) != 0;
+}
+
+void pack_record_b16(const float* w, void* dst, int nblocks, int kout, int cin, int ntaps, int Mp, int Kw, int dgrad) {
+  if (tl_pack_mode != 1) return;
+  cstp_pack_rec r{};
+  r.kind = 4; r.nblocks = nblocks; r.w = w; r.dst = dst; r.inv_a = nullptr; r.cells = nullptr;
+  const int a[6] = {kout, cin, ntaps, Mp, Kw, dgrad};
+  memcpy(r.a, a, sizeof(a));
+  tl_pack_recs.push_back(r);
 }
 
 static void pack_site_split2(hipStream_t s, const float* w, unsigned* wps, float* inv_a, unsigned* cells, int ncells, int kout,
@@ -1191,8 +1201,10 @@ pack_replay_kernel(const cstp_pack_rec* __restrict__ recs, const int* __restrict
     pack_split2_body<8>(R.w, reinterpret_cast<unsigned*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], lb);
   else if (R.kind == 2)
     pack_patch_body(R.w, reinterpret_cast<uint4*>(R.dst), R.inv_a, R.cells, a[0], a[1], a[2], a[3], a[4], a[5], a[6], lb);
-  else
+  else if (R.kind == 3)
     pack_native_body(R.w, reinterpret_cast<float*>(R.dst), a[0], a[1], a[2], a[3], a[4], a[5], a[6], lb, R.nblocks);
+  else
+    pack_w_b16_body(R.w, reinterpret_cast<unsigned short*>(R.dst), a[0], a[1], a[2], a[3], a[4], a[5], lb, R.nblocks);
 }
 
 // optional fused input transform of a convolution (see cstp_in_affine in cstp_hip.h); npg = clips per BatchNorm group

@@ -1122,10 +1122,11 @@ class _Conv3dB16(torch.autograd.Function):
         w = _req(w, "conv3d weight")
         desc = _desc(x.shape, w.shape, stride, padding)
         y = torch.empty(conv_out_shape(x.shape, w.shape, stride, padding), dtype=torch.bfloat16, device=x.device)
-        ws = _workspace(x.device, lib.cstp_b16_conv3d_workspace_bytes(ctypes.byref(desc)))
+        nbytes = lib.cstp_b16_conv3d_workspace_bytes(ctypes.byref(desc))
         with _span("conv3d_forward", lambda: ("bf16",) + _desc_key(desc)):
-            check(lib.cstp_b16_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(), ws.data_ptr(),
-                                              ws.numel()), "cstp_b16_conv3d_forward")
+            _packed_call(w_in if w.data_ptr() == w_in.data_ptr() else None, "f", x.shape, x.device, nbytes,
+                         lambda ws: check(lib.cstp_b16_conv3d_forward(_stream(), ctypes.byref(desc), x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                                                                      ws.data_ptr(), ws.numel()), "cstp_b16_conv3d_forward"))
         ctx.save_for_backward(x, w)
         ctx.w_param = w_in
         ctx.desc = desc
@@ -1163,11 +1164,12 @@ class _Conv3dB16(torch.autograd.Function):
             dw = torch.empty_like(w)
             wgrad(dw, False)
         if ctx.needs_input_grad[0]:
-            ws = _workspace(x.device, nbytes)
             dx = torch.empty_like(x)
             with _span("conv3d_backward_data", lambda: ("bf16",) + _desc_key(desc)):
-                check(lib.cstp_b16_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dx.data_ptr(),
-                                                        ws.data_ptr(), ws.numel()), "cstp_b16_conv3d_backward_data")
+                _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", x.shape, x.device, nbytes,
+                             lambda ws: check(lib.cstp_b16_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
+                                                                                dx.data_ptr(), ws.data_ptr(), ws.numel()),
+                                              "cstp_b16_conv3d_backward_data"))
         return dx, dw, None, None
 
 

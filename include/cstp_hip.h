@@ -157,11 +157,12 @@ int32_t cstp_gemm_get_split_terms(void);
  *   cstp_pack_mode(1); <the call>; cstp_pack_mode(0);  n = cstp_pack_recorded(recs, cap);     -- once: what the call packs
  *   cstp_pack_replay(stream, recs_dev, first_block_dev, n, total_blocks);                     -- per pass: all recorded packs
  *   cstp_pack_mode(2); <the same call, same pointers>; cstp_pack_mode(0);                     -- the call skips its pack
- * A record is the pack launch itself (kind 1: f16-pair split rows, 2: LDS-patch K-tiles, 3: native fp32 re-layout; pointers,
+ * A record is the pack launch itself (kind 1: f16-pair split rows, 2: LDS-patch K-tiles, 3: native fp32 re-layout, 4: the
+ * bf16-storage path's operand rows; pointers,
  * integer arguments, blocks of 256 threads), so the replay does exactly what the call would have done -- provided descriptor,
  * tile table, weight pointer and workspace pointer are those of the recorded call.  first_block_dev[i] = sum of nblocks of the
- * records before i; total_blocks = the sum over all.  The mode is per calling THREAD (0 = default).  bf16-triple packs and the
- * bf16-storage path are not recorded (they keep packing inside the call in every mode). */
+ * records before i; total_blocks = the sum over all.  The mode is per calling THREAD (0 = default).  bf16-triple packs are not
+ * recorded (they keep packing inside the call in every mode). */
 typedef struct cstp_pack_rec {
   int32_t kind, nblocks;
   const float* w;

@@ -408,3 +408,42 @@ def test_r3d_bf16_finetune_wrapper_train_and_eval_mode(name):
     finally:
         r3d.set_storage(None)
         r3d.for_depth(18)
+
+
+def test_pack_plan_covers_the_bf16_weight_packs(monkeypatch):
+    """ops.PackPlan on the bf16-storage path (record kind 4 of cstp_pack_replay: b16.hip's operand rows): seven steps of a small
+    3D-ResNet-18 with the plan (its packs replayed at the top of the step / behind the EMA, the calls skip theirs) against seven
+    steps that pack inside every call.  A stale pack -- a replay that missed the optimizer's or the EMA's update -- would show
+    from the fifth step on; bf16 weight gradients use f32 atomics, so the trajectories are compared to 1e-3."""
+    from cstp_amd.optim import FlatSGD
+    from cstp_amd.r3d_byol import R3DBYOL
+    from cstp_amd.synthetic import device_batch
+    from cstp_amd.train import PretrainStep
+    x1, x2, lab = device_batch(2, 8, 64, DEV, seed=3)
+    runs = []
+    try:
+        for plan_on in ("1", "0"):
+            monkeypatch.setenv("CSTP_PACK_PLAN", plan_on)
+            torch.manual_seed(5)
+            model = R3DBYOL(pretrain=True, opts=_opts(18, 8, 64)).cuda()
+            a = model.flatten_parameters()
+            model.train()
+            opt = FlatSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4, arenas=a)
+            step = PretrainStep(model, opt, (0.1, 1.0, 1.0, 1.0, 1.0), clip_grad_norm=True)
+            assert (step._packs is not None) == (plan_on == "1")
+            losses = []
+            for _ in range(7):
+                out = step(x1, x2, lab["spa"], lab["tem"], lab["pb"], lab["rot1"], lab["rot2"])
+                losses.append(float(out.loss_total))
+            torch.cuda.synchronize()
+            if plan_on == "1":
+                st = step._packs.stats
+                assert step._packs.state == "replay" and st["recorded_calls"] > 30, st
+                assert st["replays"] >= 2 * 3 and st["skipped_calls"] >= 3 * st["recorded_calls"] - 5, st
+                assert "target" in step._packs.tables and "online" in step._packs.tables
+            runs.append((losses, a["param"].clone(), a["target"].clone()))
+        (la, pa, ta), (lb, pb, tb) = runs
+        assert max(abs(x - y) / abs(y) for x, y in zip(la, lb)) < 1e-3, list(zip(la, lb))
+        assert float((pa - pb).abs().max() / pb.abs().max()) < 1e-2 and float((ta - tb).abs().max() / tb.abs().max()) < 1e-3
+    finally:
+        ops.pack_plan = None
