@@ -25,8 +25,10 @@
  *         table's key;
  *       * the deterministic-mode switch cstp_set_deterministic (atomic; ordered slabs instead of float atomics in the weight
  *         gradients), likewise process-wide;
- *       * environment knobs read once: CSTP_GEMM, CSTP_DETERMINISTIC, CSTP_PERSIST_CUS, CSTP_K1P_QUAD, CSTP_K1W, CSTP_TILE /
- *         CSTP_WTILE (developer overrides).
+ *       * the per-thread pack mode and record list (cstp_pack_mode) and the process-wide set of registered workspaces
+ *         (cstp_pack_register; mutex-guarded);
+ *       * environment knobs read once: CSTP_GEMM, CSTP_DETERMINISTIC, CSTP_PERSIST_CUS, CSTP_K1P_QUAD, CSTP_K1W, CSTP_LINEAR,
+ *         CSTP_BN_SMALL, CSTP_TILE / CSTP_WTILE (developer overrides).
  *     A caller that wants two arithmetics side by side in one process must serialise the switch with its launches
  *     (bench.py does, between timed loops); results never depend on the state of another STREAM.
  */
@@ -73,6 +75,9 @@ int cstp_abi_version(void);
 const char* cstp_last_error(void);
 
 /* ---- convolution (F.conv3d / F.linear and their autograd) ------------------------------- */
+/* (F.linear is the D = H = W = 1, 1x1x1 case.  On n <= 32 rows -- the heads, r21d_byol.py:159-176, 318-334 -- forward, data gradient
+ *  (reduction length a multiple of 64) and weight gradient run as weight-streaming kernels in EXACT fp32 FMAs, slices summed in a
+ *  fixed order (csrc/linear.h); CSTP_LINEAR=0, the native-f32 arithmetic and a pinned tile keep them on the convolution kernels.) */
 size_t cstp_conv3d_workspace_bytes(const cstp_conv_desc* desc);
 /* y[n][k][do][ho][wo] = conv3d(T(x), w) (+ bias[k] when bias != NULL).  w is [k][c][kt][kh][kw].
  * T = identity when in_affine == NULL, else the fused BN(+ReLU) input transform above.  (The _am variants: with an in_affine the
