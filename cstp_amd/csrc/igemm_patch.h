@@ -462,6 +462,69 @@ igemm_k1p(const PGeom g, const uint4* __restrict__ wpk, const float* __restrict_
           prow[(4 + q_gch[r]) ^ x7] = pl;
         }
       };
+#ifndef KP_DEEP
+#define KP_DEEP 1
+#endif
+      if constexpr (KP_DEEP && MT != 4 && GK == 1 && !(KP_DIAG & 1)) {
+        // ---- a whole channel block of lead (128 / 144 rows): channel block x + 2 (flat over the block's items) is REQUESTED
+        // while block x is multiplied and STORED into the free patch buffer one block later, nine K-tiles after its loads
+        // instead of four, at the first three taps of a block instead of taps 4..6.  Two register sets of three rounds (192
+        // VGPRs: the staging waves have the whole 256 of a two-waves-per-SIMD block); the set stored at block x is the one
+        // block x + 2's successor is loaded into.  No load is conditional (past the end: OOB).  Same box: S1 forward 0.742 ->
+        // 0.718 ms.  NOT at 64 rows (the data gradients' 144-channel patches, five channel blocks per item): 0.865 -> 0.898 ms
+        // there, so that instantiation keeps the four-tap schedule below.
+        unsigned qv[QR];
+        int l_it = 0, l_cb = 0, tile, mb_unused;
+        item_of(0, tile, mb_unused);
+        quad_offsets(tile, qv);
+        auto advance = [&]() __attribute__((always_inline)) {
+          if (++l_cb == g.ncb) {
+            l_cb = 0;
+            ++l_it;
+            if (l_it < nitems) { item_of(l_it, tile, mb_unused); quad_offsets(tile, qv); }
+            else {
+#pragma unroll
+              for (int r = 0; r < QR; ++r) qv[r] = OOB;
+            }
+          }
+        };
+        QRound s0[QR], s1[QR];                           // by parity of the flat channel-block index they carry
+#pragma unroll
+        for (int r = 0; r < QR; ++r) q_load(r, qv[r], l_cb, s0[r]);
+#pragma unroll
+        for (int r = 0; r < QR; ++r) q_store(0, r, s0[r]);
+        advance();
+#pragma unroll
+        for (int r = 0; r < QR; ++r) q_load(r, qv[r], l_cb, s1[r]);
+        advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int pb = 0;
+        const int total = nitems * g.ncb;
+        auto block = [&](auto ptag) __attribute__((always_inline)) {
+          constexpr int PX = decltype(ptag)::value;      // parity of the block being multiplied
+          QRound (&sst)[QR] = PX ? s0 : s1;              // block x + 1: into the free buffer now
+          QRound (&sld)[QR] = PX ? s1 : s0;              // block x + 2: requested now
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            if (tap < QR) {
+              q_store(pb ^ 1, tap, sst[tap]);
+              q_load(tap, qv[tap], l_cb, sld[tap]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          advance();
+          pb ^= 1;
+        };
+#pragma unroll 1
+        for (int x = 0; x < total; x += 2) {
+          block(std::integral_constant<int, 0>{});
+          if (x + 1 >= total) break;
+          block(std::integral_constant<int, 1>{});
+        }
+        return;
+      }
       unsigned qv_cur[QR], qv_nxt[QR];
       int tile, mb_unused;
       item_of(0, tile, mb_unused);
