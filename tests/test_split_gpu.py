@@ -23,6 +23,7 @@ GEOMS = {
     "odd": ((3, 40, 3, 9, 11), 136, (3, 3, 3), (1, 2, 1), (1, 1, 1)),           # ragged everything, 27 taps, channel padding
     "lin": ((6, 96, 1, 1, 1), 40, (1, 1, 1), (1, 1, 1), (0, 0, 0)),             # nn.Linear as a 1x1x1 convolution
     "short": ((2, 64, 4, 14, 14), 42, (1, 1, 1), (1, 2, 2), (0, 0, 0)),         # shortcut's spatial half: strided pointwise
+    "lin64": ((6, 192, 1, 1, 1), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # nn.Linear on the weight-streaming kernels (csrc/linear.h)
 }
 
 
@@ -594,9 +595,9 @@ def test_stem_weight_gradient_on_the_split_kernel(name, mt, blocks):
 
 @pytest.mark.parametrize("name,tile", [("S1", (2, 4, 0, 0)), ("S1", (1, 4, 0, 0)), ("S1", (0, 2, 1, 1)), ("S2s", (1, 9, 0, 0)),
                                        ("S2s", (0, 2, 2, 1)), ("T2s", (1, 4, 0, 0)), ("odd", (1, 3, 0, 0)), ("lin", (1, 2, 0, 0)),
-                                       ("short", (1, 4, 0, 0)), ("short", (0, 2, 2, 1))],
+                                       ("short", (1, 4, 0, 0)), ("short", (0, 2, 2, 1)), ("lin64", (1, 2, 0, 0))],
                          ids=["patch", "split", "native", "split strided", "native strided", "split temporal strided", "split odd",
-                              "split linear", "split strided pointwise", "native strided pointwise"])
+                              "split linear", "split strided pointwise", "native strided pointwise", "streaming linear"])
 def test_data_gradient_accumulate_flag(name, tile):
     """cstp_conv3d_backward_data_acc: dx += the data gradient (the sum of a residual connection's two gradients formed in the
     convolution's epilogue, ops.GradJoin) on every kernel family, incl. the stride-parity classes of a strided layer."""
@@ -628,3 +629,24 @@ def test_data_gradient_accumulate_flag(name, tile):
         assert rel_err(dx, x.grad) < TOL                             # dx = gradient
     finally:
         ops.set_split_terms(0)
+
+
+def test_streaming_linear_weight_gradient_accumulate_flag():
+    """csrc/linear.h's weight gradient (n <= 32 rows): dw += and dw = through cstp_conv3d_backward_weight_acc, ragged row count
+    (k = 40: the last block of 16 rows is partial) and whole blocks (k = 128)."""
+    from cstp_amd import _lib, ops
+    lib = _lib.load()
+    for k in (40, 128):
+        xs = (6, 192, 1, 1, 1)
+        x = _rand(xs, 71).float().cuda()
+        w = (_rand((k, xs[1], 1, 1, 1), 72) * 0.2).double().requires_grad_(True)
+        y = F.conv3d(x.double().cpu(), w, None, 1, 0)
+        dy = _rand(y.shape, 73)
+        y.backward(dy)
+        desc = ops._desc(xs, tuple(w.shape), (1, 1, 1), (0, 0, 0))
+        base = torch.full(w.shape, 0.75, device="cuda")
+        dw = base.clone()
+        _wgrad_call(lib, ops, desc, x, dy.float().cuda(), dw, 1)
+        assert rel_err(dw - base, w.grad) < TOL
+        _wgrad_call(lib, ops, desc, x, dy.float().cuda(), dw, 0)
+        assert rel_err(dw, w.grad) < TOL
