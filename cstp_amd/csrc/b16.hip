@@ -22,6 +22,8 @@
 //   split-K                    layers with few positions (14x14 / 7x7 frames) split the K loop of conv_b16_kernel over blockIdx.y
 //                              into fp32 slabs summed by b16_sum_slabs_kernel: 16 blocks x 432 K-tiles become 512 x 14.
 //   BatchNorm / pooling / cast: HBM-streaming, 16-byte (8 x bf16) accesses where rows allow.
+#include <stdlib.h>
+
 #include "common.h"
 #include "pack_b16.h"
 
@@ -972,6 +974,127 @@ b16_bn_apply_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, co
   }
 }
 
+// ---- SMALL tensors (as bn.hip's bn_small_*_kernel: <= 16 values per thread and group on blocks of 256 or 1024 threads): ONE
+// launch per pass -- a block owns a channel, group after group holds the group's values in registers, sums them in fp64, does the
+// channel's bookkeeping (b16_bn_stats_of, the running statistics group after group), applies and writes.  Half of the ~160
+// BatchNorm calls of a 3D-ResNet-50 step at configs[4]'s share are such tensors (28 x 28 and smaller), each two launches before.
+constexpr int B16_SMALL_PT = 16;
+
+__device__ __forceinline__ unsigned b16_small_off(int e, int s, int g, int npg, int c, int ch) {
+  const int r = e / s, i = e - r * s;
+  return ((unsigned)(g * npg + r) * c + ch) * s + i;       // (host: the tensor has < 2^31 elements)
+}
+
+template <int TPB>
+__global__ void __launch_bounds__(TPB)
+b16_bn_small_fwd_kernel(const u16* __restrict__ x, const u16* __restrict__ res, u16* __restrict__ y, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                        float* __restrict__ save_mean, float* __restrict__ save_invstd, float2* __restrict__ ss, int c, int s, int npg,
+                        int groups, float eps, float momentum, int relu) {
+  __shared__ double sm[16];
+  __shared__ float s_ss[2];
+  const int ch = blockIdx.x, E = npg * s;
+  const double count = (double)E;
+  const float ga = gamma[ch], be = beta[ch];
+  float rm = 0.f, rv = 0.f;
+  if (threadIdx.x == 0 && running_mean != nullptr) { rm = running_mean[ch]; rv = running_var[ch]; }
+  for (int g = 0; g < groups; ++g) {
+    float v[B16_SMALL_PT];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) {
+      const int e = u * TPB + threadIdx.x;
+      v[u] = e < E ? bf2f(x[b16_small_off(e, s, g, npg, c, ch)]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) { a0 += (double)v[u]; a1 += (double)v[u] * v[u]; }
+    a0 = block_sum(a0, sm);
+    a1 = block_sum(a1, sm);
+    if (threadIdx.x == 0) {
+      double mu, var;
+      float isf, scv, shv;
+      b16_bn_stats_of(a0, a1, count, eps, ga, be, mu, var, isf, scv, shv);
+      save_mean[g * c + ch] = (float)mu;
+      save_invstd[g * c + ch] = isf;
+      ss[g * c + ch] = make_float2(scv, shv);
+      s_ss[0] = scv; s_ss[1] = shv;
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rm = (float)((1.0 - momentum) * rm + momentum * mu);      // group after group, like successive calls
+      rv = (float)((1.0 - momentum) * rv + momentum * unb);
+    }
+    __syncthreads();
+    const float sc = s_ss[0], sh = s_ss[1];
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) {
+      const int e = u * TPB + threadIdx.x;
+      if (e >= E) continue;
+      const unsigned off = b16_small_off(e, s, g, npg, c, ch);
+      float a = __builtin_fmaf(v[u], sc, sh);
+      if (res != nullptr) a += bf2f(res[off]);
+      if (relu) a = fmaxf(a, 0.f);
+      y[off] = f2bf(a);
+    }
+    __syncthreads();                                  // s_ss is rewritten by the next group
+  }
+  if (threadIdx.x == 0 && running_mean != nullptr) { running_mean[ch] = rm; running_var[ch] = rv; }
+}
+
+__global__ void __launch_bounds__(256)
+b16_bn_small_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ y, const u16* __restrict__ dy, const float* __restrict__ gamma,
+                        const float* __restrict__ mean, const float* __restrict__ invstd, const float2* __restrict__ ss,
+                        u16* __restrict__ dx, u16* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta, int c, int s,
+                        int npg, int groups, int relu, int accumulate) {
+  __shared__ double sm[16];
+  __shared__ float s_g[2];
+  const int ch = blockIdx.x, E = npg * s;
+  const float inv_count = (float)(1.0 / (double)E);
+  const bool remask = relu && (y == nullptr);
+  const float ga = gamma[ch];
+  double t0 = 0.0, t1 = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    const int gc = g * c + ch;
+    const float mu = mean[gc], is = invstd[gc];
+    float sc = 0.f, sh = 0.f;
+    if (remask) { const float2 t2 = ss[gc]; sc = t2.x; sh = t2.y; }
+    float v[B16_SMALL_PT], gr[B16_SMALL_PT];
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      v[u] = 0.f; gr[u] = 0.f;
+      if (e < E) {
+        const unsigned off = b16_small_off(e, s, g, npg, c, ch);
+        v[u] = bf2f(x[off]);
+        float gq = bf2f(dy[off]);
+        if (remask) { if (!(__builtin_fmaf(v[u], sc, sh) > 0.f)) gq = 0.f; }
+        else if (relu && !(bf2f(y[off]) > 0.f)) gq = 0.f;
+        gr[u] = gq;
+      }
+    }
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) { a0 += (double)gr[u]; a1 += (double)(gr[u] * ((v[u] - mu) * is)); }
+    a0 = block_sum(a0, sm);
+    a1 = block_sum(a1, sm);
+    if (threadIdx.x == 0) { s_g[0] = (float)a0; s_g[1] = (float)a1; t0 += a0; t1 += a1; }
+    __syncthreads();
+    const float mb = s_g[0] * inv_count, mg = s_g[1] * inv_count;
+    const float k = ga * is;
+#pragma unroll
+    for (int u = 0; u < B16_SMALL_PT; ++u) {
+      const int e = u * 256 + threadIdx.x;
+      if (e >= E) continue;
+      const unsigned off = b16_small_off(e, s, g, npg, c, ch);
+      dx[off] = f2bf(k * (gr[u] - mb - (v[u] - mu) * is * mg));
+      if (dres != nullptr) dres[off] = f2bf(gr[u]);
+    }
+    __syncthreads();                                  // s_g is rewritten by the next group
+  }
+  if (threadIdx.x == 0) {
+    dbeta[ch] = (accumulate ? dbeta[ch] : 0.f) + (float)t0;
+    dgamma[ch] = (accumulate ? dgamma[ch] : 0.f) + (float)t1;
+  }
+}
+
 // ---- pooling ------------------------------------------------------------------------------------------------------------------
 // MaxPool3d (models/BE/r3d_byol.py:158): as maxpool3d_fwd/bwd_kernel of misc.hip on bf16 values (comparisons are exact)
 __global__ void b16_maxpool3d_fwd_kernel(const u16* __restrict__ x, u16* __restrict__ y, int32_t* __restrict__ idx, int rows, int D, int H,
@@ -1053,6 +1176,12 @@ __global__ void b16_avgpool_bwd_kernel(const float* __restrict__ dy, u16* __rest
 }  // namespace cstp
 
 using namespace cstp;
+
+// CSTP_BN_SMALL=0: every BatchNorm through the two-launch sequence (A/B switch shared with bn.hip; read once)
+static bool b16_bn_small_on() {
+  static const bool on = [] { const char* e = getenv("CSTP_BN_SMALL"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 static inline unsigned b16_grid(size_t n, int per_block) {
   size_t b = (n + per_block - 1) / per_block;
@@ -1375,6 +1504,17 @@ extern "C" int cstp_b16_bn_forward_train(void* stream, const uint16_t* x, const 
   CSTP_REQUIRE(ws && ws_bytes >= cstp_b16_bn_workspace_bytes(n, c, s, groups), "workspace too small");
   hipStream_t st = as_stream(stream);
   const int npg = n / groups, ns = b16_bn_nsplit(npg, c);
+  if (b16_bn_small_on() && (size_t)npg * s <= (size_t)B16_SMALL_PT * 1024 && (size_t)n * c * s < (1ull << 31)) {
+    float2* ss2 = reinterpret_cast<float2*>(scale_shift);
+    if ((size_t)npg * s <= (size_t)B16_SMALL_PT * 256)
+      hipLaunchKernelGGL(b16_bn_small_fwd_kernel<256>, dim3(c), dim3(256), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
+                         save_mean, save_invstd, ss2, c, s, npg, groups, eps, momentum, relu);
+    else
+      hipLaunchKernelGGL(b16_bn_small_fwd_kernel<1024>, dim3(c), dim3(1024), 0, st, x, residual, y, gamma, beta, running_mean, running_var,
+                         save_mean, save_invstd, ss2, c, s, npg, groups, eps, momentum, relu);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   double* part = reinterpret_cast<double*>(ws);
   const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
   const dim3 rgrid(c, groups * ns);
@@ -1400,6 +1540,12 @@ extern "C" int cstp_b16_bn_backward(void* stream, const uint16_t* x, const uint1
   CSTP_REQUIRE(ws && ws_bytes >= cstp_b16_bn_workspace_bytes(n, c, s, groups), "workspace too small");
   hipStream_t st = as_stream(stream);
   const int npg = n / groups, ns = b16_bn_nsplit(npg, c);
+  if (b16_bn_small_on() && (size_t)npg * s <= (size_t)B16_SMALL_PT * 256 && (size_t)n * c * s < (1ull << 31)) {
+    hipLaunchKernelGGL(b16_bn_small_bwd_kernel, dim3(c), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_invstd,
+                       reinterpret_cast<const float2*>(scale_shift), dx, dresidual, dgamma, dbeta, c, s, npg, groups, relu, accumulate ? 1 : 0);
+    CSTP_LAUNCH_CHECK();
+    return 0;
+  }
   double* part = reinterpret_cast<double*>(ws);
   const float2* ss = reinterpret_cast<const float2*>(scale_shift);
   const bool v8 = (s % 8) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |

@@ -146,7 +146,11 @@ def _bn_ref(x, gamma, beta, res, relu, groups, eps=1e-5):
 
 @pytest.mark.parametrize("shape,groups,res,relu", [((4, 64, 4, 14, 14), 2, False, True), ((4, 64, 4, 14, 14), 2, True, True),
                                                    ((4, 32, 2, 5, 5), 1, True, False), ((6, 24, 3, 7, 7), 2, False, True),
-                                                   ((8, 128, 1, 1, 1), 2, True, True), ((2, 16, 8, 56, 56), 1, False, True)])
+                                                   ((8, 128, 1, 1, 1), 2, True, True), ((2, 16, 8, 56, 56), 1, False, True),
+                                                   # the single-launch kernels' size classes (b16_bn_small_*): <= 4096 values per channel
+                                                   # and group (both passes), <= 16 384 (forward on 1024 threads), and past that
+                                                   ((8, 24, 1, 7, 7), 2, True, True), ((8, 12, 4, 28, 28), 2, True, True),
+                                                   ((8, 6, 8, 28, 28), 1, False, True)])
 def test_batch_norm_bf16_forward_backward(shape, groups, res, relu):
     g = torch.Generator().manual_seed(sum(shape))
     c = shape[1]
