@@ -126,6 +126,7 @@ SIGNATURES = {
     "cstp_b16_conv3d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cstp_b16_conv3d_forward": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
     "cstp_b16_conv3d_backward_data": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t]),
+    "cstp_b16_conv3d_backward_data_acc": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, c_int32]),
     "cstp_b16_conv3d_backward_weight": (c_int32, [_P, POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, c_int32]),
     "cstp_b16_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "cstp_b16_bn_forward_train": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,

@@ -113,6 +113,8 @@ struct B16Conv {
   int Kw;                          // elements per packed weight row
   int contig;                      // four consecutive q are four consecutive, 8-byte aligned outputs of one sample
   int n_tiles_x, n_tiles_m;
+  int acc;                         // data gradient: out = bf16(bf16(result) + out) -- the sum of a residual connection's two gradients
+                                   // formed here instead of by a separate add pass (ops.GradJoin); the rounding points are autograd's
   int ksplit;                      // > 1: blockIdx.y owns a slice of the K-tiles and leaves an fp32 partial tile in its slab
   int wf32;                        // PW forward: `wp` is the fp32 weight tensor [M][Kw] itself (k contiguous): rounded on the fly, no pack launch
   int kh, kw;                      // TAB: kernel extent (for the offset table)
@@ -407,8 +409,16 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
         const int lo = __builtin_amdgcn_ds_bpermute(perm_src, (int)pack_bf2(t4.a, t4.b));
         const int hi = __builtin_amdgcn_ds_bpermute(perm_src, (int)pack_bf2(t4.c, t4.d));
         const int m = m0 + b * 16 + sfr;
-        if (pok && m < g.M)
-          *reinterpret_cast<uint2*>(out + ((size_t)nbo * g.M + m) * DHWo + pos) = make_uint2((unsigned)lo, (unsigned)hi);
+        if (pok && m < g.M) {
+          uint2* o2 = reinterpret_cast<uint2*>(out + ((size_t)nbo * g.M + m) * DHWo + pos);
+          unsigned l2 = (unsigned)lo, h2 = (unsigned)hi;
+          if (g.acc) {
+            const uint2 old = *o2;
+            l2 = pack_bf2(bflo(l2) + bflo(old.x), bfhi(l2) + bfhi(old.x));
+            h2 = pack_bf2(bflo(h2) + bflo(old.y), bfhi(h2) + bfhi(old.y));
+          }
+          *o2 = make_uint2(l2, h2);
+        }
       }
     } else if (g.contig) {
       if (P0 >= npos) continue;
@@ -442,7 +452,10 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
         for (int r = 0; r < 4; ++r) {
           if (!ok[r]) continue;
           if (sl != nullptr) sl[ooff[r] + (size_t)m * DHWo] = v[r];
-          else out[ooff[r] + (size_t)m * DHWo] = f2bf(v[r]);
+          else {
+            u16* o1 = out + ooff[r] + (size_t)m * DHWo;
+            *o1 = g.acc ? f2bf(bf2f(f2bf(v[r])) + bf2f(*o1)) : f2bf(v[r]);
+          }
         }
       }
     }
@@ -451,18 +464,24 @@ conv_b16_kernel(const B16Conv g, const u16* __restrict__ src, const uint4* __res
 
 // out[i] = bf16(sum over the S slabs of slab[s][i]) (fixed order: bit-reproducible)
 __global__ void __launch_bounds__(256)
-b16_sum_slabs_kernel(const float* __restrict__ slab, int S, size_t stride, u16* __restrict__ out, size_t n) {
+b16_sum_slabs_kernel(const float* __restrict__ slab, int S, size_t stride, u16* __restrict__ out, size_t n, int acc = 0) {
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     f32x4 a = *reinterpret_cast<const f32x4*>(slab + 4 * i);
     for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(slab + (size_t)s * stride + 4 * i);
-    reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+    unsigned lo = pack_bf2(a[0], a[1]), hi = pack_bf2(a[2], a[3]);
+    if (acc) {                                        // (as the convolution kernel's epilogue: bf16(bf16(result) + out))
+      const uint2 old = reinterpret_cast<const uint2*>(out)[i];
+      lo = pack_bf2(bflo(lo) + bflo(old.x), bfhi(lo) + bfhi(old.x));
+      hi = pack_bf2(bflo(hi) + bflo(old.y), bfhi(hi) + bfhi(old.y));
+    }
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(lo, hi);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
     float a = slab[i];
     for (int s = 1; s < S; ++s) a += slab[(size_t)s * stride + i];
-    out[i] = f2bf(a);
+    out[i] = acc ? f2bf(bf2f(f2bf(a)) + bf2f(out[i])) : f2bf(a);
   }
 }
 
@@ -1373,6 +1392,11 @@ extern "C" int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* d, co
 
 extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc* d, const uint16_t* dy, const float* w, uint16_t* dx,
                                              void* ws, size_t ws_bytes) {
+  return cstp_b16_conv3d_backward_data_acc(stream, d, dy, w, dx, ws, ws_bytes, 0);
+}
+
+extern "C" int cstp_b16_conv3d_backward_data_acc(void* stream, const cstp_conv_desc* d, const uint16_t* dy, const float* w, uint16_t* dx,
+                                                 void* ws, size_t ws_bytes, int32_t accumulate) {
   B16Geom q;
   CSTP_REQUIRE(b16_geom(d, q), "bad convolution geometry");
   CSTP_REQUIRE(dy && w && dx && ws && ws_bytes >= cstp_b16_conv3d_workspace_bytes(d), "null argument or workspace too small");
@@ -1420,12 +1444,14 @@ extern "C" int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc*
             }
         g.ntaps = i;
         g.ksplit = ksplit;
+        g.acc = (accumulate && ksplit <= 1) ? 1 : 0;
         if (b16_octets(d, dy, q.Wo, d->w)) b16_launch_conv<false, true>(st, g, d->c, dy, wp, dx, slab, out_elems);
         else b16_launch_conv<false>(st, g, d->c, dy, wp, dx, slab, out_elems);
         CSTP_LAUNCH_CHECK();
       }
   if (ksplit > 1) {
-    hipLaunchKernelGGL(b16_sum_slabs_kernel, dim3(b16_grid(out_elems / 4 + 1, 256)), dim3(256), 0, st, slab, ksplit, out_elems, dx, out_elems);
+    hipLaunchKernelGGL(b16_sum_slabs_kernel, dim3(b16_grid(out_elems / 4 + 1, 256)), dim3(256), 0, st, slab, ksplit, out_elems, dx, out_elems,
+                       accumulate ? 1 : 0);
     CSTP_LAUNCH_CHECK();
   }
   return 0;

@@ -688,7 +688,7 @@ def conv3d(x, w, bias=None, stride=1, padding=0, bn_groups=0, bn_pivot=None, gra
     if x.dtype == torch.bfloat16:
         if bias is not None:
             raise _lib.CstpError("bf16-storage conv3d is bias-free (models/BE/r3d_byol.py:45-53)")
-        return _Conv3dB16.apply(x, w, _triple(stride), _triple(padding))
+        return _Conv3dB16.apply(x, w, _triple(stride), _triple(padding), grad_join)
     y = _Conv3d.apply(x, w, bias, _triple(stride), _triple(padding), int(bn_groups), bn_pivot, grad_join)
     st = _Conv3d._last_stats
     _Conv3d._last_stats = None
@@ -806,7 +806,7 @@ def batch_norm_act(x, gamma, beta, running_mean=None, running_var=None, residual
     A bfloat16 ``x`` (and residual) selects the bf16-storage path."""
     if x.dtype == torch.bfloat16:
         return _BNActB16.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
-                               int(groups))
+                               int(groups), grad_join)
     _BNAct._pre_stats = _bnstats_of(x, int(groups))
     y = _BNAct.apply(x, gamma, beta, residual, running_mean, running_var, bool(relu), float(eps), float(momentum),
                      int(groups), grad_join)
@@ -1115,9 +1115,10 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
 
 class _Conv3dB16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, padding):
+    def forward(ctx, x, w, stride, padding, grad_join=None):
         lib = _lib.load()
         w_in = w
+        ctx.grad_join = grad_join
         x = _req16(x, "conv3d input")
         w = _req(w, "conv3d weight")
         desc = _desc(x.shape, w.shape, stride, padding)
@@ -1164,20 +1165,27 @@ class _Conv3dB16(torch.autograd.Function):
             dw = torch.empty_like(w)
             wgrad(dw, False)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            with _span("conv3d_backward_data", lambda: ("bf16",) + _desc_key(desc)):
-                _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", x.shape, x.device, nbytes,
-                             lambda ws: check(lib.cstp_b16_conv3d_backward_data(_stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
-                                                                                dx.data_ptr(), ws.data_ptr(), ws.numel()),
-                                              "cstp_b16_conv3d_backward_data"))
-        return dx, dw, None, None
+            def dgrad(dst, acc):
+                with _span("conv3d_backward_data", lambda: ("bf16",) + _desc_key(desc)):
+                    _packed_call(ctx.w_param if w.data_ptr() == ctx.w_param.data_ptr() else None, "d", x.shape, x.device, nbytes,
+                                 lambda ws: check(lib.cstp_b16_conv3d_backward_data_acc(
+                                     _stream(), ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), dst.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     1 if acc else 0), "cstp_b16_conv3d_backward_data"))
+                return dst
+            join = ctx.grad_join
+            if join is None:
+                dx = dgrad(torch.empty_like(x), False)
+            else:       # x also feeds another op (the residual connection): the sum of the two gradients is formed here (GradJoin)
+                dx = join.contribute(lambda: dgrad(torch.empty_like(x), False), lambda buf: dgrad(buf, True))
+        return dx, dw, None, None, None
 
 
 class _BNActB16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, relu, eps, momentum, groups, grad_join=None):
         lib = _lib.load()
         ctx.param_objs = (gamma, beta)     # the parameter objects themselves (their .grad may be an arena slice)
+        ctx.grad_join = grad_join
         x = _req16(x, "batch_norm input")
         gamma = _req(gamma, "batch_norm weight")
         beta = _req(beta, "batch_norm bias")
@@ -1226,7 +1234,9 @@ class _BNActB16(torch.autograd.Function):
                                            1 if direct else 0), "cstp_b16_bn_backward")
         if direct:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        if dres is not None and ctx.grad_join is not None:       # the residual tensor's other consumer adds its gradient to this
+            dres = ctx.grad_join.contribute(lambda: dres, lambda buf: buf.add_(dres))
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 class _MaxPool3dB16(torch.autograd.Function):

@@ -408,6 +408,10 @@ int cstp_b16_conv3d_forward(void* stream, const cstp_conv_desc* desc, const uint
 /* its autograd backward w.r.t. the input: dx[n][c][d][h][w] bf16 (every element written). */
 int cstp_b16_conv3d_backward_data(void* stream, const cstp_conv_desc* desc, const uint16_t* dy, const float* w, uint16_t* dx,
                                   void* ws, size_t ws_bytes);
+/* ... accumulate != 0: dx = bf16(bf16(gradient) + dx) -- the second gradient of a tensor that feeds two ops (a residual
+ * connection) added in the epilogue instead of by a separate add pass; the rounding points are those of the add it replaces. */
+int cstp_b16_conv3d_backward_data_acc(void* stream, const cstp_conv_desc* desc, const uint16_t* dy, const float* w, uint16_t* dx,
+                                  void* ws, size_t ws_bytes, int32_t accumulate);
 /* ... and w.r.t. the weight: dw[k][c][kt][kh][kw] fp32, accumulate != 0: dw += (position splits through fp32 slabs summed in
  * a fixed order: bit-reproducible). */
 int cstp_b16_conv3d_backward_weight(void* stream, const cstp_conv_desc* desc, const uint16_t* x, const uint16_t* dy, float* dw,
